@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (TEST INFRASTRUCTURE ONLY; runs in the build container
+where /root/reference is mounted - never on the GPU box).
+
+    cd /root/repo && python oracle/gen_goldens.py
+
+Imports the REFERENCE's own Python (lib.models.*, lib.common.{camera,crop,affine})
+from /root/reference, drives it with the seeded synthetic weights/inputs of
+absolutetrack_amd.synth, and writes small fixtures (inputs that cannot be
+regenerated + expected outputs) under tests/golden/:
+
+  model_known.npz / model_unknown.npz   reference UmeTrackModel outputs (rows a3-a10)
+  geometry_rec00.npz                    reference crop cameras + warp coordinate maps (a1,a2)
+  fk_user05.npz                         label poses + the reference's STORED gt_keypoints (a12)
+and the label data the bench/tests drive the path with:
+  absolutetrack_amd/data/recording_00_labels.npz   (from sample_data/recording_00.json)
+
+Not importable in this image, hence NOT run here: lib.common.hand_skinning /
+lib.tracker.perspective_crop (pytorch3d), lib.tracker.tracker (cv2),
+lib.tracker.video_pose_data (av).  No stand-ins are written for them.
+"""
+import json
+import os
+import sys
+
+REF = "/root/reference"
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REF)          # the reference's `lib` must win over the repo's drop-in `lib`
+sys.path.insert(1, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from absolutetrack_amd import arch, synth  # noqa: E402
+from oracle import ref_camera, ref_fk, scenarios, stored_eval  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+DATA = os.path.join(REPO, "absolutetrack_amd", "data")
+
+
+# ----------------------------------------------------------------------------- reference model
+def build_reference_model():
+    import lib.models.feature_extractor as fe
+    import lib.models.skeleton_encoder as se
+    import lib.models.temporal as tem
+    from lib.models.model_loader import _create_regressor
+    from lib.models.model_opts import ModelOpts
+    from lib.models.umetrack_model import UmeTrackModel
+    assert fe.__file__.startswith(REF), fe.__file__
+    mo = ModelOpts()
+    f = fe.FeatureExtractor((96, 96), mo)
+    model = UmeTrackModel(
+        feature_extractor=f,
+        temporal=tem.create_temporal_model(mo, f.output_feature_sizes),
+        skeleton_encoder=se.SkeletonEncoder([mo.nSkeletonFeatureChannels, *f.output_feature_sizes]),
+        regressor_k=_create_regressor(mo, f.output_feature_sizes, use_skel=True, predict_skel_scale=False),
+        regressor_u=_create_regressor(mo, f.output_feature_sizes, use_skel=False, predict_skel_scale=True),
+    )
+    sd = {k: torch.from_numpy(v) for k, v in synth.synthetic_state_dict(0).items()}
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    return model
+
+
+def run_model_scenario(known: bool):
+    from lib.models.umetrack_model import InputFrameData, InputFrameDesc, InputSkeletonData
+    model = build_reference_model()
+    taps = {}
+    bb = model._feature_extractor._image_backbone
+    hooks = [bb[0]._layers[0].register_forward_hook(lambda m, i, o: taps.__setitem__("stem", o)),
+             bb[0]._layers[1].register_forward_hook(lambda m, i, o: taps.__setitem__("layer1", o)),
+             bb[0]._layers[2].register_forward_hook(lambda m, i, o: taps.__setitem__("layer2", o)),
+             bb[0]._layers[3].register_forward_hook(lambda m, i, o: taps.__setitem__("layer3", o)),
+             bb[0]._layers[4].register_forward_hook(lambda m, i, o: taps.__setitem__("layer4", o)),
+             bb[1].register_forward_hook(lambda m, i, o: taps.__setitem__("proj", o)),
+             model._temporal.register_forward_hook(lambda m, i, o: None)]
+    reg = model._regressor_k if known else model._regressor_u
+    hooks.append(reg._pose_regression_layers.register_forward_hook(
+        lambda m, i, o: taps.__setitem__("raw", o.flatten(1))))
+    out = {}
+    steps = scenarios.model_steps(known)
+    skel = scenarios.skeleton_m()
+    with torch.no_grad():
+        for si, st in enumerate(steps):
+            fd = InputFrameData(left_images=torch.from_numpy(st["images"]),
+                                intrinsics=torch.from_numpy(st["intrinsics"]),
+                                extrinsics_xf=torch.from_numpy(st["extrinsics"]))
+            desc = InputFrameDesc(sample_range=torch.from_numpy(st["sample_range"]),
+                                  memory_idx=torch.from_numpy(st["memory_idx"]),
+                                  use_memory=torch.from_numpy(st["use_memory"]),
+                                  hand_idx=torch.from_numpy(st["hand_idx"]))
+            if known:
+                sk = InputSkeletonData(joint_rotation_axes=torch.from_numpy(skel[0]),
+                                       joint_rest_positions=torch.from_numpy(skel[1]))
+                r = model.regress_pose_use_skeleton(fd, desc, sk)
+            else:
+                r = model.regress_pose_pred_skel_scale(fd, desc)
+            p = f"s{si}."
+            out[p + "joint_angles"] = r.joint_angles.numpy()
+            out[p + "wrist_xfs"] = r.wrist_xfs.numpy()
+            out[p + "sigmas"] = r.landmark_uncertainty_sigmas.numpy()
+            if r.skel_scales is not None:
+                out[p + "skel_scales"] = r.skel_scales.numpy()
+            out[p + "raw"] = taps["raw"].numpy()
+            out[p + "proj"] = taps["proj"].numpy()
+            out[p + "mem_state"] = model._temporal._mem_features.numpy().copy()
+            out[p + "prev_ext_state"] = model._temporal._prev_extrinsics.numpy().copy()
+            if si == 0:   # early layers only once, spatially subsampled to keep the fixture small
+                out["s0.stem_sub"] = taps["stem"][:, :, ::6, ::6].numpy()
+                out["s0.layer1_sub"] = taps["layer1"][:, :, ::6, ::6].numpy()
+                out["s0.layer2_sub"] = taps["layer2"][:, :, ::3, ::3].numpy()
+                out["s0.layer3_sub"] = taps["layer3"][:, ::2, ::2, ::2].numpy()
+                out["s0.layer4_sub"] = taps["layer4"][:, ::4].numpy()
+    for h in hooks:
+        h.remove()
+    return out
+
+
+# ----------------------------------------------------------------------------- labels / FK
+HM_FIELDS = ("joint_rotation_axes", "joint_rest_positions", "landmark_rest_positions",
+             "landmark_rest_bone_weights", "landmark_rest_bone_indices", "joint_limits")
+
+
+def hand_model_arrays(hm: dict, prefix="hm."):
+    return {prefix + k: np.asarray(hm[k], np.float32 if k != "landmark_rest_bone_indices" else np.int32)
+            for k in HM_FIELDS}
+
+
+def export_labels():
+    d = json.load(open(os.path.join(REF, "sample_data", "recording_00.json")))
+    cams = d["cameras"]
+    names = ("ImageSizeX", "ImageSizeY", "fx", "fy", "cx", "cy", "k1", "k2", "k3", "k4", "p1", "p2", "k5", "k6")
+    assert all(c["DistortionModel"] == "FishEye62" for c in cams)
+    out = {"cameras": np.array([[c[n] for n in names] for c in cams], np.float64),
+           "camera_angles": np.asarray(d["camera_angles"], np.float64),
+           "joint_angles": np.asarray(d["joint_angles"], np.float64),
+           "wrist_transforms": np.asarray(d["wrist_transforms"], np.float64),
+           "hand_confidences": np.asarray(d["hand_confidences"], np.float64),
+           "camera_to_world_transforms": np.asarray(d["camera_to_world_transforms"], np.float64)}
+    out.update(hand_model_arrays(d["hand_model"]))
+    os.makedirs(DATA, exist_ok=True)
+    np.savez_compressed(os.path.join(DATA, "recording_00_labels.npz"), **out)
+    return d
+
+
+def export_fk():
+    out = {}
+    for rec in ("00", "02", "11"):
+        d = json.load(open(os.path.join(REF, "sample_data", "user05", f"recording_{rec}.json")))
+        st = stored_eval.read_stored_eval(os.path.join(REF, "sample_data", "user05", f"recording_{rec}.npy"))
+        sel = np.arange(0, len(d["joint_angles"]), 9)
+        p = f"r{rec}."
+        out[p + "joint_angles"] = np.asarray(d["joint_angles"], np.float64)[sel]
+        out[p + "wrist_transforms"] = np.asarray(d["wrist_transforms"], np.float64)[sel]
+        out[p + "hand_confidences"] = np.asarray(d["hand_confidences"], np.float64)[sel]
+        out[p + "gt_keypoints"] = st["gt_keypoints"][:, sel]                 # [2,T,21,3] mm
+        out[p + "valid_tracking"] = st["valid_tracking"][:, sel]
+        out.update(hand_model_arrays(d["hand_model"], p + "hm."))
+    np.savez_compressed(os.path.join(GOLD, "fk_user05.npz"), **out)
+
+
+# ----------------------------------------------------------------------------- geometry
+def export_geometry(labels: dict):
+    import lib.common.camera as rcam
+    import lib.common.crop as rcrop
+    assert rcam.__file__.startswith(REF)
+    hm = {k: np.asarray(labels["hand_model"][k]) for k in HM_FIELDS}
+    frames = list(range(0, 369, 40))
+    out = {"frames": np.array(frames)}
+    for fi in frames:
+        cams = []
+        for ci, cj in enumerate(labels["cameras"]):
+            c = rcam.read_camera_from_json(cj)
+            cams.append(c.copy(camera_to_world_xf=np.asarray(labels["camera_to_world_transforms"][fi][ci])))
+        for hand in (0, 1):
+            ja = np.asarray(labels["joint_angles"][fi][hand])
+            wx = np.asarray(labels["wrist_transforms"][fi][hand])
+            # crop points: FK of (label pose, neutral pose, open pose) - FK itself is pinned separately
+            lim = hm["joint_limits"].astype(np.float32)
+            poses = (ja, lim[:, 0] * np.float32(0.5) + lim[:, 1] * np.float32(0.5), np.zeros(22, np.float32))
+            pts = np.concatenate([ref_camera.landmarks_from_pose(hm, p, wx, hand) for p in poses], 0)
+            lm = pts[:21]
+            vis = []
+            for c in cams:     # reference camera maths for the visibility count (perspective_crop.py:64-76)
+                eye = c.world_to_eye(lm)
+                win = c.eye_to_window(eye)
+                vis.append(int(((win[..., 0] >= 0) & (win[..., 0] <= c.width - 1) & (win[..., 1] >= 0)
+                                & (win[..., 1] <= c.height - 1) & (eye[..., 2] > 0)).sum()))
+            key = f"f{fi}.h{hand}."
+            out[key + "crop_points"] = pts
+            out[key + "visible"] = np.array(vis)
+            order = [i for i in range(4) if vis[i] >= 19]
+            order.sort(reverse=True, key=lambda i: vis[i])
+            order = sorted(order)[:2]
+            out[key + "cams"] = np.array(order)
+            for ci in order:
+                crop = rcrop.gen_crop_parameters_from_points(
+                    cams[ci], pts, (96, 96), mirror_img_x=(hand == 1),
+                    camera_angle=labels["camera_angles"][ci], focal_multiplier=0.8)
+                ck = key + f"c{ci}."
+                out[ck + "f"] = np.asarray(crop.f, np.float64)
+                out[ck + "c"] = np.asarray(crop.c, np.float64)
+                out[ck + "T"] = np.asarray(crop.camera_to_world_xf, np.float64)
+                out[ck + "K"] = np.asarray(crop.uv_to_window_matrix(), np.float64)
+                # the coordinate map of lib/tracker/tracker.py:68-85, through the reference's camera methods
+                px, py = np.meshgrid(np.arange(96), np.arange(96))
+                dst = np.column_stack((px.flatten(), py.flatten()))
+                seye = cams[ci].world_to_eye(crop.eye_to_world(crop.window_to_eye(dst)))
+                swin = cams[ci].eye_to_window(seye)
+                swin[seye[:, 2] < 0] = -1
+                out[ck + "map_sub"] = swin.astype(np.float32).reshape(96, 96, 2)[::4, ::4]
+    np.savez_compressed(os.path.join(GOLD, "geometry_rec00.npz"), **out)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    labels = export_labels()
+    export_fk()
+    export_geometry(labels)
+    np.savez_compressed(os.path.join(GOLD, "model_known.npz"), **run_model_scenario(True))
+    np.savez_compressed(os.path.join(GOLD, "model_unknown.npz"), **run_model_scenario(False))
+    for f in sorted(os.listdir(GOLD)):
+        print(f, os.path.getsize(os.path.join(GOLD, f)))
+
+
+if __name__ == "__main__":
+    main()

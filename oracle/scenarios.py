@@ -1,0 +1,85 @@
+"""Seeded input scenarios shared by the golden generator and the parity tests
+(TEST INFRASTRUCTURE ONLY).  Everything is regenerated from the counter-based RNG of
+absolutetrack_amd.synth, so the fixtures under tests/golden/ only hold OUTPUTS.
+
+The model scenarios exercise, per SURVEY.md section 8(c) G2: a mixed 1-view/2-view
+batch, three consecutive temporal steps with use_memory F->T->T, a slot drop,
+permuted slots with state growth, both hand indices and both regress modes.
+"""
+import os
+from typing import Dict, List
+
+import numpy as np
+
+from absolutetrack_amd import synth
+
+_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                     "absolutetrack_amd", "data", "recording_00_labels.npz")
+
+
+def labels() -> Dict[str, np.ndarray]:
+    return dict(np.load(_DATA))
+
+
+def hand_model_mm() -> Dict[str, np.ndarray]:
+    lab = labels()
+    return {k[3:]: v for k, v in lab.items() if k.startswith("hm.")}
+
+
+def skeleton_m():
+    """(axes [22,3], rest [22,3] in metres) as HandTracker._make_inputs builds them
+    (lib/tracker/tracker.py:361-367: scaled_hand_model(hand_model_mm, 0.001))."""
+    hm = hand_model_mm()
+    return (hm["joint_rotation_axes"].astype(np.float32),
+            (hm["joint_rest_positions"] * np.float32(0.001)).astype(np.float32))
+
+
+def _rigid(key: str, n: int, seed: int) -> np.ndarray:
+    """n world->eye extrinsics: random rotation (axis-angle, |angle| < 1.2 rad), t ~ U(-0.3,0.3) m."""
+    u = synth.counter_uniform(key, n * 6, seed).reshape(n, 6) * 2 - 1
+    out = np.zeros((n, 4, 4), np.float64)
+    for i in range(n):
+        v = u[i, :3] * 1.2 / np.sqrt(3)
+        th = np.linalg.norm(v)
+        k = np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+        r = np.eye(3) + np.sin(th) / th * k + (1 - np.cos(th)) / th ** 2 * (k @ k)
+        out[i, :3, :3] = r
+        out[i, :3, 3] = u[i, 3:] * 0.3
+        out[i, 3, 3] = 1
+    return out.astype(np.float32)
+
+
+def _intrinsics(key: str, n: int, seed: int) -> np.ndarray:
+    f = 100 + 60 * synth.counter_uniform(key, n, seed)
+    k = np.zeros((n, 3, 3), np.float32)
+    k[:, 0, 0] = k[:, 1, 1] = f
+    k[:, 0, 2] = k[:, 1, 2] = 47.5
+    k[:, 2, 2] = 1
+    return k
+
+
+def _step(tag: str, seed: int, sample_range, memory_idx, use_memory, hand_idx) -> dict:
+    sample_range = np.asarray(sample_range, np.int64)
+    n = int(sample_range[-1, 1])
+    return {"images": synth.synthetic_crops(n, seed=100 + seed),
+            "intrinsics": _intrinsics(tag + ".K", n, seed),
+            "extrinsics": _rigid(tag + ".X", n, seed),
+            "sample_range": sample_range,
+            "memory_idx": np.asarray(memory_idx, np.int64),
+            "use_memory": np.asarray(use_memory, bool),
+            "hand_idx": np.asarray(hand_idx, np.int64)}
+
+
+def model_steps(known: bool) -> List[dict]:
+    if known:
+        return [
+            _step("k", 0, [[0, 2], [2, 3], [3, 5]], [0, 1, 2], [False, False, False], [0, 1, 1]),
+            _step("k", 1, [[0, 2], [2, 3], [3, 5]], [0, 1, 2], [True, True, True], [0, 1, 1]),
+            _step("k", 2, [[0, 1], [1, 3]], [1, 2], [True, False], [1, 0]),            # slot 0 dropped
+            _step("k", 3, [[0, 2], [2, 4], [4, 6], [6, 8]], [3, 0, 1, 2], [False, True, True, True], [0, 1, 0, 1]),
+        ]
+    return [
+        _step("u", 0, [[0, 2], [2, 4]], [0, 1], [False, False], [0, 1]),
+        _step("u", 1, [[0, 2], [2, 4], [4, 6], [6, 8]], [3, 0, 1, 2], [False, True, True, False], [1, 0, 1, 0]),
+        _step("u", 2, [[0, 2], [2, 4]], [2, 0], [True, True], [0, 0]),
+    ]
