@@ -1,0 +1,305 @@
+"""ctypes binding of libumetrack_hip.so (include/umetrack_hip.h).
+
+There is no CPU fallback: if the shared library is missing or no HIP device is
+present, every entry point raises.  PyTorch-ROCm is used for device memory and
+streams only; tensors cross the boundary as raw device pointers.
+"""
+import ctypes
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import arch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libumetrack_hip.so")
+
+EXPORTS = (
+    "ut_weight_blob_floats", "ut_create", "ut_destroy", "ut_last_error", "ut_reserve",
+    "ut_set_backbone_chunk", "ut_warp_crops", "ut_backbone", "ut_fuse_temporal_regress",
+    "ut_reset_memory", "ut_get_memory", "ut_fk", "ut_profile_begin", "ut_profile_end",
+)
+
+UT_MODE_KNOWN, UT_MODE_UNKNOWN = 0, 1
+UT_REMAP_CV2_FIXED, UT_REMAP_FLOAT = 0, 1
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load_library() -> ctypes.CDLL:
+    """dlopen the in-tree library and declare the prototypes.  Raises loudly when absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, f32p = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
+    lib.ut_weight_blob_floats.restype = ctypes.c_size_t
+    lib.ut_weight_blob_floats.argtypes = []
+    lib.ut_create.restype = i32
+    lib.ut_create.argtypes = [i32, vp, ctypes.c_size_t, ctypes.POINTER(vp)]
+    lib.ut_destroy.restype = i32
+    lib.ut_destroy.argtypes = [vp]
+    lib.ut_last_error.restype = ctypes.c_char_p
+    lib.ut_last_error.argtypes = [vp]
+    lib.ut_reserve.restype = i32
+    lib.ut_reserve.argtypes = [vp, i32, i32, i32]
+    lib.ut_set_backbone_chunk.restype = i32
+    lib.ut_set_backbone_chunk.argtypes = [vp, i32]
+    lib.ut_warp_crops.restype = i32
+    lib.ut_warp_crops.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i32, i32, f32p, vp]
+    lib.ut_backbone.restype = i32
+    lib.ut_backbone.argtypes = [vp, f32p, i32, f32p, vp]
+    lib.ut_fuse_temporal_regress.restype = i32
+    lib.ut_fuse_temporal_regress.argtypes = [vp, f32p, f32p, f32p, vp, vp, vp, vp, i32, i32, i32, i32,
+                                             f32p, i32, i32, f32p, f32p, vp]
+    lib.ut_reset_memory.restype = i32
+    lib.ut_reset_memory.argtypes = [vp]
+    lib.ut_get_memory.restype = i32
+    lib.ut_get_memory.argtypes = [vp, f32p, f32p, i32, vp]
+    lib.ut_fk.restype = i32
+    lib.ut_fk.argtypes = [vp, f32p, i32, f32p, i32, f32p, i32, vp, ctypes.c_float, i32, f32p, vp]
+    lib.ut_profile_begin.restype = i32
+    lib.ut_profile_begin.argtypes = [vp, vp]
+    lib.ut_profile_end.restype = i32
+    lib.ut_profile_end.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
+                                   ctypes.POINTER(ctypes.c_double)]
+    _lib = lib
+    return lib
+
+
+def state_dict_to_blob(state_dict) -> np.ndarray:
+    """Flatten a reference-keyed state dict (torch tensors or numpy arrays) in the order of
+    arch.state_dict_spec() to the fp32 blob ut_create expects.  Strict like load_state_dict."""
+    spec = arch.state_dict_spec()
+    missing = [k for k, _s, _kind in spec if k not in state_dict]
+    extra = [k for k in state_dict if k not in {k for k, _s, _kind in spec}]
+    if missing or extra:
+        raise RuntimeError(f"Error(s) in loading state_dict: missing keys {missing[:4]}..., "
+                           f"unexpected keys {extra[:4]}..." if missing or extra else "")
+    parts = []
+    for k, shape, _kind in spec:
+        v = state_dict[k]
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        v = np.asarray(v)
+        if tuple(v.shape) != tuple(shape):
+            raise RuntimeError(f"size mismatch for {k}: expected {tuple(shape)}, got {tuple(v.shape)}")
+        parts.append(v.astype(np.float32).reshape(-1))
+    blob = np.ascontiguousarray(np.concatenate(parts))
+    assert blob.size == 4_259_410
+    return blob
+
+
+def hand_model_blob(joint_rotation_axes, joint_rest_positions, landmark_rest_positions,
+                    landmark_rest_bone_weights, landmark_rest_bone_indices) -> np.ndarray:
+    """[...,321] fp32 packing of the HandModel fields the FK kernel reads (lib/common/hand.py:48-62)."""
+    def a(x, tail):
+        if isinstance(x, torch.Tensor):
+            x = x.detach().cpu().numpy()
+        x = np.asarray(x, np.float32)
+        return x.reshape(x.shape[: x.ndim - len(tail)] + (-1,))
+    parts = [a(joint_rotation_axes, (22, 3)), a(joint_rest_positions, (22, 3)), a(landmark_rest_positions, (21, 3)),
+             a(landmark_rest_bone_weights, (21, 3)), a(landmark_rest_bone_indices, (21, 3))]
+    lead = np.broadcast_shapes(*[p.shape[:-1] for p in parts])
+    return np.ascontiguousarray(np.concatenate([np.broadcast_to(p, lead + p.shape[-1:]) for p in parts], -1))
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _need(t: torch.Tensor, dtype, device, name: str) -> torch.Tensor:
+    if t.device != device:
+        raise ValueError(f"{name} must live on {device}, got {t.device}")
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def fk_stateless(hand_model: torch.Tensor, joint_angles: torch.Tensor, wrist_xf: torch.Tensor,
+                 mirror: Optional[torch.Tensor] = None, t_scale: float = 1.0) -> torch.Tensor:
+    """ut_fk without a model handle (the FK kernel needs no network weights).  All tensors on one HIP device."""
+    lib = load_library()
+    d = joint_angles.device
+    if d.type != "cuda":
+        raise NativeLibraryError("fk_stateless needs tensors on a HIP device (no CPU fallback)")
+    hand_model = _need(hand_model, torch.float32, d, "hand_model").reshape(-1, 321)
+    joint_angles = _need(joint_angles, torch.float32, d, "joint_angles").reshape(-1, 22)
+    wrist_xf = _need(wrist_xf, torch.float32, d, "wrist_xf").reshape(-1, 16)
+    n = joint_angles.shape[0]
+    if mirror is not None:
+        mirror = _need(mirror, torch.int64, d, "mirror").reshape(-1)
+    out = torch.empty(n, arch.N_LANDMARKS, 3, dtype=torch.float32, device=d)
+    with torch.cuda.device(d):
+        rc = lib.ut_fk(None, _ptr(hand_model), hand_model.shape[0], _ptr(joint_angles), 22, _ptr(wrist_xf), 16,
+                       _ptr(mirror), ctypes.c_float(t_scale), n, _ptr(out), _stream(d))
+    if rc != 0:
+        raise RuntimeError(f"ut_fk failed ({rc}): {lib.ut_last_error(None).decode()}")
+    return out
+
+
+class HipEngine:
+    """One native handle (packed weights + workspace + temporal state) on one GPU."""
+
+    def __init__(self, state_dict, device="cuda"):
+        if not torch.cuda.is_available():
+            raise NativeLibraryError("no HIP device visible: the UmeTrack hot path has no CPU fallback")
+        self.lib = load_library()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise NativeLibraryError(f"device {device!r} is not a HIP device")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        blob = state_dict_to_blob(state_dict)
+        h = ctypes.c_void_p()
+        rc = self.lib.ut_create(self.device.index, blob.ctypes.data_as(ctypes.c_void_p), blob.size, ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"ut_create failed ({rc}): {self.lib.ut_last_error(None).decode()}")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.ut_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc < 0:
+            msg = self.lib.ut_last_error(self._h).decode()
+            if rc == -4:
+                raise AssertionError(msg)      # the reference asserts here (umetrack_model.py:224-229)
+            raise RuntimeError(f"{what} failed ({rc}): {msg}")
+        return rc
+
+    # ------------------------------------------------------------------ entry points
+    def reserve(self, max_crops: int, max_samples: int, max_slots: int):
+        self._check(self.lib.ut_reserve(self._h, max_crops, max_samples, max_slots), "ut_reserve")
+
+    def set_backbone_chunk(self, crops: int):
+        self._check(self.lib.ut_set_backbone_chunk(self._h, crops), "ut_set_backbone_chunk")
+
+    def warp_crops(self, src_u8: torch.Tensor, cam_params: torch.Tensor, crop_params: torch.Tensor,
+                   src_index: torch.Tensor, mode: int = UT_REMAP_CV2_FIXED,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        d = self.device
+        src_u8 = _need(src_u8, torch.uint8, d, "src")
+        if src_u8.dim() != 3:
+            raise ValueError("src must be [n_images, H, W] uint8")
+        cam_params = _need(cam_params, torch.float64, d, "cam_params")
+        crop_params = _need(crop_params, torch.float64, d, "crop_params")
+        src_index = _need(src_index, torch.int32, d, "src_index")
+        n = crop_params.shape[0]
+        if cam_params.shape != (src_u8.shape[0], 32) or crop_params.shape != (n, 24) or src_index.shape != (n,):
+            raise ValueError("bad cam_params / crop_params / src_index shape")
+        if out is None:
+            out = torch.empty(n, arch.CROP, arch.CROP, dtype=torch.float32, device=d)
+        self._check(self.lib.ut_warp_crops(self._h, _ptr(src_u8), src_u8.shape[0], src_u8.shape[1], src_u8.shape[2],
+                                           _ptr(cam_params), _ptr(crop_params), _ptr(src_index), n, mode, _ptr(out),
+                                           _stream(d)), "ut_warp_crops")
+        return out
+
+    def backbone(self, crops: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        d = self.device
+        crops = _need(crops, torch.float32, d, "crops")
+        if crops.dim() != 3 or crops.shape[1:] != (arch.CROP, arch.CROP):
+            raise ValueError(f"crops must be [n,96,96], got {tuple(crops.shape)}")
+        n = crops.shape[0]
+        if out is None:
+            out = torch.empty(n, arch.FEAT_CH, arch.FEAT_HW, arch.FEAT_HW, dtype=torch.float32, device=d)
+        self._check(self.lib.ut_backbone(self._h, _ptr(crops), n, _ptr(out), _stream(d)), "ut_backbone")
+        return out
+
+    def fuse_temporal_regress(self, feat, intrinsics, extrinsics, sample_range, memory_idx, use_memory, hand_idx,
+                              n_slots: int, all_multiview: bool, skel: Optional[torch.Tensor], mode: int,
+                              want_raw: bool = False, out: Optional[torch.Tensor] = None
+                              ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        d = self.device
+        feat = _need(feat, torch.float32, d, "feat")
+        intrinsics = _need(intrinsics, torch.float32, d, "intrinsics")
+        extrinsics = _need(extrinsics, torch.float32, d, "extrinsics")
+        sample_range = _need(sample_range, torch.int64, d, "sample_range")
+        memory_idx = _need(memory_idx, torch.int64, d, "memory_idx")
+        hand_idx = _need(hand_idx, torch.int64, d, "hand_idx")
+        use_memory = _need(use_memory.to(torch.uint8) if use_memory.dtype == torch.bool else use_memory,
+                           torch.uint8, d, "use_memory")
+        n, s = feat.shape[0], sample_range.shape[0]
+        if intrinsics.shape != (n, 3, 3) or extrinsics.shape != (n, 4, 4) or sample_range.shape != (s, 2) \
+                or memory_idx.shape != (s,) or use_memory.shape != (s,) or hand_idx.shape != (s,):
+            raise ValueError("inconsistent frame data / frame desc shapes")
+        n_skel = 0
+        if skel is not None:
+            skel = _need(skel, torch.float32, d, "skel")
+            n_skel = skel.shape[0]
+        if out is None:
+            out = torch.empty(s, arch.POSE_REC, dtype=torch.float32, device=d)
+        raw = torch.empty(s, 64, dtype=torch.float32, device=d) if want_raw else None
+        self._check(self.lib.ut_fuse_temporal_regress(
+            self._h, _ptr(feat), _ptr(intrinsics), _ptr(extrinsics), _ptr(sample_range), _ptr(memory_idx),
+            _ptr(use_memory), _ptr(hand_idx), n, s, int(n_slots), int(bool(all_multiview)), _ptr(skel), n_skel, mode,
+            _ptr(out), _ptr(raw), _stream(d)), "ut_fuse_temporal_regress")
+        return out, raw
+
+    def reset_memory(self):
+        self._check(self.lib.ut_reset_memory(self._h), "ut_reset_memory")
+
+    def get_memory(self, max_slots: int = 1 << 16):
+        d = self.device
+        n = self._check(self.lib.ut_get_memory(self._h, None, None, 0, _stream(d)), "ut_get_memory")
+        n = min(n, max_slots)
+        mem = torch.empty(n, arch.MEM_CH, arch.FEAT_HW, arch.FEAT_HW, dtype=torch.float32, device=d)
+        ext = torch.empty(n, 4, 4, dtype=torch.float32, device=d)
+        if n:
+            self._check(self.lib.ut_get_memory(self._h, _ptr(mem), _ptr(ext), n, _stream(d)), "ut_get_memory")
+        return mem, ext
+
+    def fk(self, hand_model: torch.Tensor, joint_angles: torch.Tensor, wrist_xf: torch.Tensor,
+           mirror: Optional[torch.Tensor] = None, t_scale: float = 1.0, ja_stride: int = 22, xf_stride: int = 16,
+           n: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """hand_model [1|n,321]; joint_angles/wrist_xf either packed [n,22]/[n,4,4] or views into a pose
+        record buffer with explicit strides (in floats)."""
+        d = self.device
+        hand_model = _need(hand_model, torch.float32, d, "hand_model").reshape(-1, 321)
+        if n is None:
+            joint_angles = _need(joint_angles, torch.float32, d, "joint_angles").reshape(-1, 22)
+            wrist_xf = _need(wrist_xf, torch.float32, d, "wrist_xf").reshape(-1, 16)
+            n = joint_angles.shape[0]
+            if wrist_xf.shape[0] != n:
+                raise ValueError("joint_angles / wrist_xf batch mismatch")
+        if mirror is not None:
+            mirror = _need(mirror, torch.int64, d, "mirror").reshape(-1)
+            if mirror.shape[0] != n:
+                raise ValueError("mirror batch mismatch")
+        if out is None:
+            out = torch.empty(n, arch.N_LANDMARKS, 3, dtype=torch.float32, device=d)
+        self._check(self.lib.ut_fk(self._h, _ptr(hand_model), hand_model.shape[0], _ptr(joint_angles), ja_stride,
+                                   _ptr(wrist_xf), xf_stride, _ptr(mirror), ctypes.c_float(t_scale), n, _ptr(out),
+                                   _stream(d)), "ut_fk")
+        return out
+
+    def profile_begin(self):
+        self._check(self.lib.ut_profile_begin(self._h, _stream(self.device)), "ut_profile_begin")
+
+    def profile_end(self):
+        ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        self._check(self.lib.ut_profile_end(self._h, _stream(self.device), ctypes.byref(ms), ctypes.byref(n),
+                                            ctypes.byref(fl)), "ut_profile_end")
+        return ms.value, n.value, fl.value

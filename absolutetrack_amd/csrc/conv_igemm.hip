@@ -1,0 +1,203 @@
+// Implicit-GEMM convolution for gfx950 on the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Replaces every Conv2d(+BatchNorm2d)(+residual)(+ReLU) of the reference after the stem:
+// lib/models/backbone_resnet.py:56-72 (BasicBlock), lib/models/model_utils.py:134 (projection),
+// :141-163 (fusion), lib/models/temporal.py:31-38, lib/models/model_utils.py:195-208 (regressor).
+//
+// GEMM view: M = n_img*Ho*Wo output pixels, N = cout, K = taps*cin with k = tap*cin + c.
+// Activations are NHWC so a k-run of 4 channels is one 16-byte load; weights are pre-packed
+// [cout_pad][k_pad] (k contiguous) with BatchNorm folded in.  A workgroup (4 waves, 256 threads)
+// owns a BM x BN output tile and walks K in chunks of 32:
+//   global (im2col gather, zero fill at the borders) -> registers -> LDS (double buffered,
+//   rows padded to 36 floats so ds_read_b128 fragment reads are bank-conflict free)
+//   -> one ds_read_b128 per 32-row fragment per 8 k  -> 4 MFMA 32x32x2 per fragment pair.
+// Lane l of a wave holds row (l&31) of the fragment and k-half (l>>5); the 4 floats of a b128
+// read feed 4 consecutive MFMAs (k order inside the 8-run is permuted identically for A and B).
+// Epilogue: bias (+residual) (+ReLU) from the accumulator layout col = lane&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#include "ut_kernels.h"
+
+namespace ut {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int LDS_ROW = BK + 4;   // floats; 144 B row stride = 9 x 16 B -> conflict-free b128 reads
+
+template <int BM, int BN, int WR, int WC>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvLaunch p) {
+  static_assert(WR * WC == 4, "4 waves per workgroup");
+  constexpr int MI = BM / WR / 32;   // 32x32 accumulator tiles per wave along M
+  constexpr int NI = BN / WC / 32;   // ... along N
+  constexpr int AP = BM / 32;        // 16-byte loads per thread per chunk for the A tile
+  constexpr int BP = BN / 32;
+  constexpr int STAGE = (BM + BN) * LDS_ROW;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WC, wn = wave % WC;
+  const int g = tid & 7;        // which 4-float group of the 32-wide k chunk this thread stages
+  const int r0 = tid >> 3;      // first tile row this thread stages (then +32 per pass)
+
+  const int M = p.n_img * p.Ho * p.Wo;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  // ---- per-thread im2col row bookkeeping (fixed over the K loop)
+  const float* a_base[AP];
+  int a_iy[AP], a_ix[AP];
+  bool a_ok[AP];
+#pragma unroll
+  for (int i = 0; i < AP; ++i) {
+    int m = m0 + r0 + 32 * i;
+    a_ok[i] = m < M;
+    int mm = a_ok[i] ? m : 0;
+    int img = mm / (p.Ho * p.Wo);
+    int rem = mm - img * (p.Ho * p.Wo);
+    int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    a_iy[i] = oy * p.stride - p.pad;
+    a_ix[i] = ox * p.stride - p.pad;
+    a_base[i] = p.in + (size_t)img * p.H * p.W * p.cin;
+  }
+  const float* b_ptr = p.w + (size_t)(n0 + r0) * p.k_pad + 4 * g;
+
+  // (tap, channel) of this thread's 4-float group, advanced by 32 per chunk
+  int kc = 4 * g;              // k index of the group in the current chunk
+  int tap = kc / p.cin;
+  int ch = kc - tap * p.cin;
+
+  float4 a_reg[AP], b_reg[BP];
+
+  auto fetch = [&](int chunk) {
+    (void)chunk;
+    int dy = 0, dx = 0;
+    if (p.ksize == 3) { dy = tap / 3; dx = tap - 3 * dy; }
+    const bool k_ok = kc < p.k_total;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+      bool ok = a_ok[i] && k_ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) v = *reinterpret_cast<const float4*>(a_base[i] + ((size_t)(iy * p.W + ix) * p.cin + ch));
+      a_reg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i)
+      b_reg[i] = *reinterpret_cast<const float4*>(b_ptr + (size_t)(32 * i) * p.k_pad);
+    // advance to the next chunk
+    b_ptr += BK;
+    kc += BK;
+    ch += BK;
+    while (ch >= p.cin) { ch -= p.cin; ++tap; }
+  };
+
+  auto stage = [&](int buf) {
+    float* as = smem + buf * STAGE;
+    float* bs = as + BM * LDS_ROW;
+#pragma unroll
+    for (int i = 0; i < AP; ++i)
+      *reinterpret_cast<float4*>(as + (r0 + 32 * i) * LDS_ROW + 4 * g) = a_reg[i];
+#pragma unroll
+    for (int i = 0; i < BP; ++i)
+      *reinterpret_cast<float4*>(bs + (r0 + 32 * i) * LDS_ROW + 4 * g) = b_reg[i];
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int n_chunks = p.k_pad / BK;
+  const int fr = lane & 31;          // fragment row
+  const int fh = lane >> 5;          // k half
+
+  fetch(0);
+  stage(0);
+  __syncthreads();
+
+  for (int c = 0; c < n_chunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < n_chunks) fetch(c + 1);
+    const float* as = smem + buf * STAGE + (wm * (MI * 32) + fr) * LDS_ROW + 4 * fh;
+    const float* bs = smem + buf * STAGE + BM * LDS_ROW + (wn * (NI * 32) + fr) * LDS_ROW + 4 * fh;
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) {
+      float4 af[MI], bf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDS_ROW + 8 * q);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_ROW + 8 * q);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (c + 1 < n_chunks) stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue
+  const int hw = p.Ho * p.Wo;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = n0 + wn * (NI * 32) + j * 32 + fr;
+    const bool n_ok = n < p.cout_store;
+    const float bias = p.bias[n];   // bias is padded to cout_pad
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * (MI * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (n_ok && m < M) {
+          float v = acc[i][j][e] + bias;
+          size_t o;
+          if (p.out_nchw) {
+            int img = m / hw;
+            o = ((size_t)img * p.cout_store + n) * hw + (m - img * hw);
+          } else {
+            o = (size_t)m * p.cout_store + n;
+          }
+          if (p.res) v += p.res[o];
+          if (p.relu) v = fmaxf(v, 0.f);
+          p.out[o] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WR, int WC>
+static hipError_t launch_cfg(const ConvLaunch& c, hipStream_t s) {
+  const int M = c.n_img * c.Ho * c.Wo;
+  dim3 grid((M + BM - 1) / BM, (c.cout_store + BN - 1) / BN);
+  size_t lds = 2 * (size_t)(BM + BN) * LDS_ROW * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC>), grid, dim3(256), lds, s, c);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv_igemm(const ConvLaunch& c, hipStream_t s) {
+  if (c.cin % 4 != 0 || c.k_pad % BK != 0 || c.cout_pad % 128 != 0) return hipErrorInvalidValue;
+  if (c.cout_store <= 32) return launch_cfg<128, 32, 4, 1>(c, s);
+  if (c.cout_store <= 64) return launch_cfg<128, 64, 2, 2>(c, s);
+  return launch_cfg<128, 128, 2, 2>(c, s);
+}
+
+}  // namespace ut

@@ -1,0 +1,79 @@
+// Stem of the backbone: Conv2d(1,32,3,pad=1,bias) + BatchNorm2d + ReLU + MaxPool2d(2)
+// (lib/models/model_utils.py:119-124), BatchNorm folded into the 32x9 weights.
+// cin = 1, K = 9: not an MFMA shape - direct convolution on the vector ALU.
+// One workgroup = one crop x 4 pooled rows; the 10 x 96 input rows it needs are staged in LDS
+// with a zero halo.  One thread = one pooled pixel x 4 output channels (a 16-byte NHWC store;
+// 8 threads cover the 32 channels = one 128-byte line per pixel).
+#include "ut_kernels.h"
+
+namespace ut {
+
+constexpr int CROP = 96, POOLED = 48, STEM_C = 32;
+constexpr int ROWS_PER_WG = 4;                 // pooled rows per workgroup
+constexpr int IN_ROWS = 2 * ROWS_PER_WG + 2;   // input rows incl. halo
+constexpr int IN_COLS = CROP + 2;
+
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ crops,
+                                                   const float* __restrict__ w,
+                                                   const float* __restrict__ bias,
+                                                   float* __restrict__ out, int n) {
+  __shared__ float tile[IN_ROWS][IN_COLS + 2];
+  __shared__ float ws[STEM_C * 9 + STEM_C];
+  const int img = blockIdx.y;
+  const int prow0 = blockIdx.x * ROWS_PER_WG;
+  const float* src = crops + (size_t)img * CROP * CROP;
+  for (int i = threadIdx.x; i < STEM_C * 9 + STEM_C; i += 256) ws[i] = i < STEM_C * 9 ? w[i] : bias[i - STEM_C * 9];
+  for (int i = threadIdx.x; i < IN_ROWS * IN_COLS; i += 256) {
+    int r = i / IN_COLS, c = i - r * IN_COLS;
+    int y = 2 * prow0 - 1 + r, x = c - 1;
+    tile[r][c] = (y >= 0 && y < CROP && x >= 0 && x < CROP) ? src[y * CROP + x] : 0.f;
+  }
+  __syncthreads();
+  // 4 rows x 48 pooled pixels x 8 channel groups = 1536 work items, 6 per thread
+  for (int item = threadIdx.x; item < ROWS_PER_WG * POOLED * 8; item += 256) {
+    const int cg = item & 7;
+    const int pix = item >> 3;
+    const int pr = pix / POOLED, pc = pix - pr * POOLED;
+    float in[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) in[a][b] = tile[2 * pr + a][2 * pc + b];
+    float res[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float* wk = ws + (cg * 4 + k) * 9;
+      float best = -3.4e38f;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          float acc = 0.f;
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc = fmaf(in[dy + ky][dx + kx], wk[ky * 3 + kx], acc);
+          best = fmaxf(best, acc);
+        }
+      res[k] = fmaxf(best + ws[STEM_C * 9 + cg * 4 + k], 0.f);
+    }
+    float* o = out + (((size_t)img * POOLED + prow0 + pr) * POOLED + pc) * STEM_C + cg * 4;
+    *reinterpret_cast<float4*>(o) = make_float4(res[0], res[1], res[2], res[3]);
+  }
+}
+
+hipError_t launch_stem(const float* crops, const float* w, const float* bias, float* out, int n,
+                       hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  // grid.y is limited to 65535: split very large batches
+  for (int done = 0; done < n;) {
+    int cnt = n - done < 32768 ? n - done : 32768;
+    hipLaunchKernelGGL(stem_kernel, dim3(POOLED / ROWS_PER_WG, cnt), dim3(256), 0, s,
+                       crops + (size_t)done * CROP * CROP, w, bias,
+                       out + (size_t)done * POOLED * POOLED * STEM_C, cnt);
+    done += cnt;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace ut

@@ -1,0 +1,550 @@
+// C ABI of libumetrack_hip.so (include/umetrack_hip.h): handle, weight folding/packing, workspace,
+// temporal state and the launch sequences of the hot path.  Host-only logic; kernels live in the
+// other translation units.
+#include "../../include/umetrack_hip.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "ut_kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct ConvW {
+  float* w = nullptr;     // device [cout_pad][k_pad]
+  float* bias = nullptr;  // device [cout_pad]
+  int cin = 0, cin_pad = 0, cout = 0, cout_pad = 0, cout_store = 0;
+  int taps = 1, ksize = 1, stride = 1, pad = 0, k_total = 0, k_pad = 0;
+  double flops_per_pixel = 0;   // 2 * taps * cin * cout, un-padded
+};
+
+struct Block {
+  ConvW conv1, conv2, ds;
+  bool has_ds = false;
+};
+
+struct Regressor {
+  Block blocks[2];
+  float* w_out = nullptr;   // [D][C] raw (applied after the average pool)
+  float* b_out = nullptr;
+  int c = 0, d = 0;
+};
+
+struct ProfEvent { hipEvent_t a, b; double flops; };
+
+}  // namespace
+
+struct ut_context {
+  int device = 0;
+  std::string err;
+  std::vector<void*> allocs;        // everything to hipFree at destroy
+  // weights
+  float* stem_w = nullptr; float* stem_b = nullptr;
+  Block bb[12];
+  ConvW proj, fus0, fus1, fus2, tmp[3];
+  float *skel_w = nullptr, *skel_b = nullptr, *skel_scale = nullptr, *skel_shift = nullptr;
+  Regressor reg_k, reg_u;
+  // backbone workspace (per pass of `chunk` crops)
+  int chunk = 256;
+  int ws_crops = 0;
+  float *bufX = nullptr, *bufH = nullptr, *bufY = nullptr, *bufD = nullptr;
+  // head workspace
+  int ws_samples = 0;
+  ut::HeadBuffers hb{};
+  int ws_skel = 0;
+  // temporal state
+  int slots_cap = 0, slots_used = 0;
+  float *mem = nullptr, *prev_ext = nullptr;
+  // profiling
+  bool profiling = false;
+  std::vector<ProfEvent> prof;
+};
+
+namespace {
+
+int fail(ut_handle h, int code, const char* what, hipError_t e = hipSuccess) {
+  char buf[512];
+  if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+  else snprintf(buf, sizeof buf, "%s", what);
+  if (h) h->err = buf; else g_create_error = buf;
+  return code;
+}
+
+#define HIPCHK(h, x)                                            \
+  do {                                                          \
+    hipError_t e_ = (x);                                        \
+    if (e_ != hipSuccess) return fail(h, UT_E_HIP, #x, e_);     \
+  } while (0)
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct Cursor {
+  const float* p;
+  size_t left;
+  const float* take(size_t n) {
+    if (n > left) { left = 0; ok = false; return nullptr; }
+    const float* r = p; p += n; left -= n; return r;
+  }
+  bool ok = true;
+};
+
+struct BN { const float *g = nullptr, *b = nullptr, *m = nullptr, *v = nullptr; };
+
+BN take_bn(Cursor& c, int ch) {
+  BN bn;
+  bn.g = c.take(ch); bn.b = c.take(ch); bn.m = c.take(ch); bn.v = c.take(ch);
+  c.take(1);   // num_batches_tracked
+  return bn;
+}
+
+int upload(ut_handle h, const std::vector<float>& host, float** dev) {
+  void* d = nullptr;
+  HIPCHK(h, hipMalloc(&d, host.size() * sizeof(float)));
+  h->allocs.push_back(d);
+  HIPCHK(h, hipMemcpy(d, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  *dev = (float*)d;
+  return UT_OK;
+}
+
+// Fold eval-mode BatchNorm (eps 1e-5) into the convolution and pack to [cout_pad][k_pad] with
+// k = tap*cin_pad + c.   y = s*(conv(x)+b-mean)+beta,  s = gamma/sqrt(var+eps)
+int pack_conv(ut_handle h, ConvW& cw, const float* w, const float* conv_bias, const BN* bn, int cin, int cout,
+              int ksize, int stride, int cout_store) {
+  cw.cin = cin; cw.cout = cout; cw.ksize = ksize; cw.stride = stride;
+  cw.pad = ksize == 3 ? 1 : 0;
+  cw.taps = ksize * ksize;
+  cw.cin_pad = round_up(cin, 4);
+  cw.cout_store = cout_store;
+  cw.cout_pad = round_up(cout_store, 128);
+  cw.k_total = cw.taps * cw.cin_pad;
+  cw.k_pad = round_up(cw.k_total, 32);
+  cw.flops_per_pixel = 2.0 * cw.taps * cin * cout;
+  std::vector<float> wp((size_t)cw.cout_pad * cw.k_pad, 0.f), bp(cw.cout_pad, 0.f);
+  for (int o = 0; o < cout; ++o) {
+    double s = 1.0, shift = conv_bias ? (double)conv_bias[o] : 0.0;
+    if (bn) {
+      s = (double)bn->g[o] / sqrt((double)bn->v[o] + 1e-5);
+      shift = (shift - (double)bn->m[o]) * s + (double)bn->b[o];
+    }
+    bp[o] = (float)shift;
+    for (int c = 0; c < cin; ++c)
+      for (int t = 0; t < cw.taps; ++t)
+        wp[(size_t)o * cw.k_pad + t * cw.cin_pad + c] = (float)((double)w[((size_t)o * cin + c) * cw.taps + t] * s);
+  }
+  int rc = upload(h, wp, &cw.w);
+  if (rc) return rc;
+  return upload(h, bp, &cw.bias);
+}
+
+int take_block(ut_handle h, Cursor& c, Block& b, int cin, int cout, int stride, bool ds) {
+  const float* w1 = c.take((size_t)cout * cin * 9);
+  BN bn1 = take_bn(c, cout);
+  const float* w2 = c.take((size_t)cout * cout * 9);
+  BN bn2 = take_bn(c, cout);
+  const float* wd = nullptr;
+  BN bnd;
+  if (ds) { wd = c.take((size_t)cout * cin); bnd = take_bn(c, cout); }
+  if (!c.ok) return fail(h, UT_E_WEIGHTS, "weight blob too short");
+  int rc;
+  if ((rc = pack_conv(h, b.conv1, w1, nullptr, &bn1, cin, cout, 3, stride, round_up(cout, 4)))) return rc;
+  if ((rc = pack_conv(h, b.conv2, w2, nullptr, &bn2, cout, cout, 3, 1, round_up(cout, 4)))) return rc;
+  b.has_ds = ds;
+  if (ds && (rc = pack_conv(h, b.ds, wd, nullptr, &bnd, cin, cout, 1, stride, round_up(cout, 4)))) return rc;
+  return UT_OK;
+}
+
+int take_regressor(ut_handle h, Cursor& c, Regressor& r, int ch, int d) {
+  r.c = ch; r.d = d;
+  int rc;
+  for (int i = 0; i < 2; ++i)
+    if ((rc = take_block(h, c, r.blocks[i], ch, ch, 1, false))) return rc;
+  const float* w = c.take((size_t)d * ch);
+  const float* b = c.take(d);
+  if (!c.ok) return fail(h, UT_E_WEIGHTS, "weight blob too short");
+  if ((rc = upload(h, std::vector<float>(w, w + (size_t)d * ch), &r.w_out))) return rc;
+  return upload(h, std::vector<float>(b, b + d), &r.b_out);
+}
+
+int dev_alloc(ut_handle h, float** p, size_t n_floats) {
+  void* d = nullptr;
+  HIPCHK(h, hipMalloc(&d, n_floats * sizeof(float)));
+  h->allocs.push_back(d);
+  *p = (float*)d;
+  return UT_OK;
+}
+
+void dev_free(ut_handle h, void* p) {
+  if (!p) return;
+  for (size_t i = 0; i < h->allocs.size(); ++i)
+    if (h->allocs[i] == p) { h->allocs.erase(h->allocs.begin() + i); break; }
+  (void)hipFree(p);
+}
+
+int ensure_backbone_ws(ut_handle h, int crops) {
+  if (crops <= h->ws_crops) return UT_OK;
+  HIPCHK(h, hipDeviceSynchronize());
+  dev_free(h, h->bufX); dev_free(h, h->bufH); dev_free(h, h->bufY); dev_free(h, h->bufD);
+  h->bufX = h->bufH = h->bufY = h->bufD = nullptr;
+  h->ws_crops = 0;
+  const size_t big = (size_t)crops * 48 * 48 * 32, small = (size_t)crops * 24 * 24 * 64;
+  int rc;
+  if ((rc = dev_alloc(h, &h->bufX, big)) || (rc = dev_alloc(h, &h->bufH, big)) ||
+      (rc = dev_alloc(h, &h->bufY, big)) || (rc = dev_alloc(h, &h->bufD, small)))
+    return rc;
+  h->ws_crops = crops;
+  return UT_OK;
+}
+
+int ensure_head_ws(ut_handle h, int samples, int n_skel) {
+  int rc;
+  if (samples > h->ws_samples) {
+    HIPCHK(h, hipDeviceSynchronize());
+    float** ptrs[] = {&h->hb.cat144, &h->hb.f108, &h->hb.f72a, &h->hb.f72b, &h->hb.fused, &h->hb.t92a,
+                      &h->hb.t92b, &h->hb.regin, &h->hb.rega, &h->hb.regb};
+    const int ch[] = {144, 108, 72, 72, 72, 92, 92, 76, 76, 76};
+    for (int i = 0; i < 10; ++i) {
+      dev_free(h, *ptrs[i]);
+      *ptrs[i] = nullptr;
+    }
+    h->ws_samples = 0;
+    for (int i = 0; i < 10; ++i)
+      if ((rc = dev_alloc(h, ptrs[i], (size_t)samples * 36 * ch[i]))) return rc;
+    h->ws_samples = samples;
+  }
+  if (n_skel > h->ws_skel) {
+    HIPCHK(h, hipDeviceSynchronize());
+    dev_free(h, h->hb.skel);
+    h->hb.skel = nullptr;
+    h->ws_skel = 0;
+    if ((rc = dev_alloc(h, &h->hb.skel, (size_t)n_skel * 36 * 4))) return rc;
+    h->ws_skel = n_skel;
+  }
+  return UT_OK;
+}
+
+int ensure_slots(ut_handle h, int slots, hipStream_t s) {
+  if (slots <= h->slots_cap) return UT_OK;
+  int cap = h->slots_cap ? h->slots_cap : 2;
+  while (cap < slots) cap *= 2;
+  float *nm = nullptr, *ne = nullptr;
+  int rc;
+  if ((rc = dev_alloc(h, &nm, (size_t)cap * 36 * 18)) || (rc = dev_alloc(h, &ne, (size_t)cap * 16))) return rc;
+  HIPCHK(h, hipMemsetAsync(nm, 0, (size_t)cap * 36 * 18 * sizeof(float), s));
+  HIPCHK(h, hipMemsetAsync(ne, 0, (size_t)cap * 16 * sizeof(float), s));
+  if (h->slots_cap) {
+    HIPCHK(h, hipMemcpyAsync(nm, h->mem, (size_t)h->slots_cap * 36 * 18 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(ne, h->prev_ext, (size_t)h->slots_cap * 16 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    dev_free(h, h->mem);
+    dev_free(h, h->prev_ext);
+  }
+  h->mem = nm; h->prev_ext = ne; h->slots_cap = cap;
+  return UT_OK;
+}
+
+int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, float* out, int n_img, int H, int W,
+             bool relu, bool nchw, hipStream_t s) {
+  ut::ConvLaunch c{};
+  c.in = in; c.w = cw.w; c.bias = cw.bias; c.res = res; c.out = out;
+  c.n_img = n_img; c.H = H; c.W = W; c.cin = cw.cin_pad;
+  c.Ho = (H + 2 * cw.pad - cw.ksize) / cw.stride + 1;
+  c.Wo = (W + 2 * cw.pad - cw.ksize) / cw.stride + 1;
+  c.cout_store = cw.cout_store; c.cout_pad = cw.cout_pad;
+  c.k_total = cw.k_total; c.k_pad = cw.k_pad;
+  c.ksize = cw.ksize; c.stride = cw.stride; c.pad = cw.pad;
+  c.relu = relu; c.out_nchw = nchw;
+  ProfEvent pe{};
+  if (h->profiling) {
+    HIPCHK(h, hipEventCreate(&pe.a));
+    HIPCHK(h, hipEventCreate(&pe.b));
+    pe.flops = cw.flops_per_pixel * (double)n_img * c.Ho * c.Wo;
+    HIPCHK(h, hipEventRecord(pe.a, s));
+  }
+  HIPCHK(h, ut::launch_conv_igemm(c, s));
+  if (h->profiling) {
+    HIPCHK(h, hipEventRecord(pe.b, s));
+    h->prof.push_back(pe);
+  }
+  return UT_OK;
+}
+
+// relu(bn2(conv2(relu(bn1(conv1 x)))) + (downsample(x) | x))   lib/models/backbone_resnet.py:56-72
+int run_block(ut_handle h, const Block& b, const float* x, float* tmp, float* dsbuf, float* y, int n_img, int H,
+              int W, hipStream_t s) {
+  int rc;
+  if ((rc = run_conv(h, b.conv1, x, nullptr, tmp, n_img, H, W, true, false, s))) return rc;
+  const int Ho = (H + 2 - 3) / b.conv1.stride + 1, Wo = (W + 2 - 3) / b.conv1.stride + 1;
+  const float* res = x;
+  if (b.has_ds) {
+    if ((rc = run_conv(h, b.ds, x, nullptr, dsbuf, n_img, H, W, false, false, s))) return rc;
+    res = dsbuf;
+  }
+  return run_conv(h, b.conv2, tmp, res, y, n_img, Ho, Wo, true, false, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ut_weight_blob_floats(void) { return UT_WEIGHT_BLOB_FLOATS; }
+
+const char* ut_last_error(ut_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int ut_create(int device, const float* blob, size_t n_floats, ut_handle* out) {
+  if (!blob || !out) return fail(nullptr, UT_E_INVALID, "ut_create: null argument");
+  if (n_floats != UT_WEIGHT_BLOB_FLOATS) return fail(nullptr, UT_E_WEIGHTS, "ut_create: weight blob has the wrong length");
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(nullptr, UT_E_HIP, "hipSetDevice", e);
+  ut_handle h = new ut_context();
+  h->device = device;
+  Cursor c{blob, n_floats};
+  int rc = UT_OK;
+  do {
+    // stem (lib/models/model_utils.py:119-124)
+    const float* sw = c.take(32 * 9);
+    const float* sb = c.take(32);
+    BN sbn = take_bn(c, 32);
+    std::vector<float> w(32 * 9), b(32);
+    for (int o = 0; o < 32; ++o) {
+      double s = (double)sbn.g[o] / sqrt((double)sbn.v[o] + 1e-5);
+      for (int t = 0; t < 9; ++t) w[o * 9 + t] = (float)((double)sw[o * 9 + t] * s);
+      b[o] = (float)(((double)sb[o] - (double)sbn.m[o]) * s + (double)sbn.b[o]);
+    }
+    if ((rc = upload(h, w, &h->stem_w)) || (rc = upload(h, b, &h->stem_b))) break;
+    // ResNet layers "2352", planes 32/64/128/256, strides 1/2/2/2 (lib/models/backbone_resnet.py:168-192)
+    const int nb[4] = {2, 3, 5, 2}, planes[4] = {32, 64, 128, 256}, strides[4] = {1, 2, 2, 2};
+    int cin = 32, bi = 0;
+    for (int l = 0; l < 4 && !rc; ++l)
+      for (int k = 0; k < nb[l] && !rc; ++k) {
+        int st = k == 0 ? strides[l] : 1;
+        bool ds = k == 0 && (st != 1 || cin != planes[l]);
+        rc = take_block(h, c, h->bb[bi++], cin, planes[l], st, ds);
+        cin = planes[l];
+      }
+    if (rc) break;
+    const float* pw = c.take(72 * 256); const float* pb = c.take(72);
+    if (!c.ok) { rc = fail(h, UT_E_WEIGHTS, "weight blob too short"); break; }
+    if ((rc = pack_conv(h, h->proj, pw, pb, nullptr, 256, 72, 1, 1, 72))) break;
+    // fusion 144 -> 108 -> 72 -> 72 (lib/models/model_utils.py:141-163)
+    { const float* w0 = c.take(108 * 144); const float* b0 = c.take(108); BN bn0 = take_bn(c, 108);
+      const float* w1 = c.take(72 * 108); const float* b1 = c.take(72); BN bn1 = take_bn(c, 72);
+      const float* w2 = c.take(72 * 72); const float* b2 = c.take(72);
+      if (!c.ok) { rc = fail(h, UT_E_WEIGHTS, "weight blob too short"); break; }
+      if ((rc = pack_conv(h, h->fus0, w0, b0, &bn0, 144, 108, 1, 1, 108)) ||
+          (rc = pack_conv(h, h->fus1, w1, b1, &bn1, 108, 72, 1, 1, 72)) ||
+          (rc = pack_conv(h, h->fus2, w2, b2, nullptr, 72, 72, 1, 1, 72))) break; }
+    // temporal 90 -> 90 x3 on a 92-channel padded layout (lib/models/temporal.py:31-38)
+    for (int i = 0; i < 3 && !rc; ++i) {
+      const float* tw = c.take(90 * 90); const float* tb = c.take(90);
+      if (!c.ok) { rc = fail(h, UT_E_WEIGHTS, "weight blob too short"); break; }
+      rc = pack_conv(h, h->tmp[i], tw, tb, nullptr, 90, 90, 1, 1, 92);
+    }
+    if (rc) break;
+    // skeleton encoder (lib/models/skeleton_encoder.py:36-41)
+    { const float* lw = c.take(144 * 132); const float* lb = c.take(144); BN bn = take_bn(c, 4);
+      if (!c.ok) { rc = fail(h, UT_E_WEIGHTS, "weight blob too short"); break; }
+      std::vector<float> sc(4), sh(4);
+      for (int k = 0; k < 4; ++k) {
+        double s = (double)bn.g[k] / sqrt((double)bn.v[k] + 1e-5);
+        sc[k] = (float)s; sh[k] = (float)((double)bn.b[k] - (double)bn.m[k] * s);
+      }
+      if ((rc = upload(h, std::vector<float>(lw, lw + 144 * 132), &h->skel_w)) ||
+          (rc = upload(h, std::vector<float>(lb, lb + 144), &h->skel_b)) ||
+          (rc = upload(h, sc, &h->skel_scale)) || (rc = upload(h, sh, &h->skel_shift))) break; }
+    if ((rc = take_regressor(h, c, h->reg_k, 76, 62))) break;
+    if ((rc = take_regressor(h, c, h->reg_u, 72, 63))) break;
+    if (!c.ok || c.left != 0) { rc = fail(h, UT_E_WEIGHTS, "weight blob length does not match the architecture"); break; }
+  } while (0);
+  if (rc) {
+    g_create_error = h->err;
+    ut_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return UT_OK;
+}
+
+int ut_destroy(ut_handle h) {
+  if (!h) return UT_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  for (void* p : h->allocs) (void)hipFree(p);
+  for (auto& pe : h->prof) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+  delete h;
+  return UT_OK;
+}
+
+int ut_set_backbone_chunk(ut_handle h, int crops_per_pass) {
+  if (!h || crops_per_pass < 0) return fail(h, UT_E_INVALID, "ut_set_backbone_chunk: bad argument");
+  h->chunk = crops_per_pass == 0 ? 256 : crops_per_pass;
+  return UT_OK;
+}
+
+int ut_reserve(ut_handle h, int max_crops, int max_samples, int max_slots) {
+  if (!h) return UT_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc;
+  int c = max_crops < h->chunk ? max_crops : h->chunk;
+  if (c > 0 && (rc = ensure_backbone_ws(h, c))) return rc;
+  if (max_samples > 0 && (rc = ensure_head_ws(h, max_samples, max_samples))) return rc;
+  if (max_slots > 0 && (rc = ensure_slots(h, max_slots, 0))) return rc;
+  return UT_OK;
+}
+
+int ut_warp_crops(ut_handle h, const uint8_t* src, int n_src_images, int src_h, int src_w, const double* cam_params,
+                  const double* crop_params, const int32_t* src_index, int n_crops, int remap_mode, float* out,
+                  void* stream) {
+  // stateless: h may be NULL
+  if (n_crops == 0) return UT_OK;
+  if (!src || !cam_params || !crop_params || !src_index || !out || n_crops < 0 || src_h <= 0 || src_w <= 0 ||
+      n_src_images <= 0 || (remap_mode != UT_REMAP_CV2_FIXED && remap_mode != UT_REMAP_FLOAT))
+    return fail(h, UT_E_INVALID, "ut_warp_crops: bad argument");
+  HIPCHK(h, ut::launch_warp(src, n_src_images, src_h, src_w, cam_params, crop_params, src_index, n_crops, remap_mode,
+                            out, (hipStream_t)stream));
+  return UT_OK;
+}
+
+int ut_backbone(ut_handle h, const float* crops, int n_crops, float* feat, void* stream) {
+  if (!h) return UT_E_INVALID;
+  if (n_crops == 0) return UT_OK;
+  if (!crops || !feat || n_crops < 0) return fail(h, UT_E_INVALID, "ut_backbone: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  const int chunk = n_crops < h->chunk ? n_crops : h->chunk;
+  if ((rc = ensure_backbone_ws(h, chunk))) return rc;
+  for (int done = 0; done < n_crops; done += chunk) {
+    const int n = n_crops - done < chunk ? n_crops - done : chunk;
+    HIPCHK(h, ut::launch_stem(crops + (size_t)done * 96 * 96, h->stem_w, h->stem_b, h->bufX, n, s));
+    float *x = h->bufX, *y = h->bufY;
+    int hw = 48;
+    for (int b = 0; b < 12; ++b) {
+      if ((rc = run_block(h, h->bb[b], x, h->bufH, h->bufD, y, n, hw, hw, s))) return rc;
+      hw = (hw + 2 - 3) / h->bb[b].conv1.stride + 1;
+      float* t = x; x = y; y = t;
+    }
+    // projection 256 -> 72, written NCHW like the reference (lib/models/model_utils.py:134)
+    if ((rc = run_conv(h, h->proj, x, nullptr, feat + (size_t)done * 72 * 36, n, 6, 6, false, true, s))) return rc;
+  }
+  return UT_OK;
+}
+
+int ut_fuse_temporal_regress(ut_handle h, const float* feat, const float* intrinsics, const float* extrinsics,
+                             const int64_t* sample_range, const int64_t* memory_idx, const uint8_t* use_memory,
+                             const int64_t* hand_idx, int n_crops, int n_samples, int n_slots, int all_multiview,
+                             const float* skel, int n_skel, int mode, float* out_pose, float* out_raw, void* stream) {
+  if (!h) return UT_E_INVALID;
+  if (n_samples == 0) return UT_OK;
+  if (!feat || !intrinsics || !extrinsics || !sample_range || !memory_idx || !use_memory || !hand_idx || !out_pose ||
+      n_samples < 0 || n_crops < n_samples || n_crops > 2 * n_samples || n_slots <= 0)
+    return fail(h, UT_E_INVALID, "ut_fuse_temporal_regress: bad argument");
+  if (mode == UT_MODE_KNOWN_SKELETON) {
+    if (!skel || (n_skel != 1 && n_skel != n_samples))
+      return fail(h, UT_E_INVALID, "ut_fuse_temporal_regress: skeleton must have 1 or n_samples entries");
+  } else if (mode == UT_MODE_UNKNOWN_SKELETON) {
+    // lib/models/umetrack_model.py:224-229
+    if (!all_multiview)
+      return fail(h, UT_E_UNSUPPORTED, "Unsupported: found single-view samples when calibration scale");
+    n_skel = 0;
+  } else {
+    return fail(h, UT_E_INVALID, "ut_fuse_temporal_regress: unknown mode");
+  }
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if ((rc = ensure_head_ws(h, n_samples, n_skel))) return rc;
+  if ((rc = ensure_slots(h, n_slots, s))) return rc;
+  if (n_slots > h->slots_used) h->slots_used = n_slots;
+  ut::HeadArgs a{};
+  a.feat = feat; a.intrinsics = intrinsics; a.extrinsics = extrinsics; a.sample_range = sample_range;
+  a.memory_idx = memory_idx; a.use_memory = use_memory; a.hand_idx = hand_idx; a.n_samples = n_samples;
+  a.mem = h->mem; a.prev_ext = h->prev_ext;
+  const ut::HeadBuffers& b = h->hb;
+  const int S = n_samples;
+  HIPCHK(h, ut::launch_ftl_in(a, b, s));
+  if ((rc = run_conv(h, h->fus0, b.cat144, nullptr, b.f108, S, 6, 6, true, false, s))) return rc;
+  if ((rc = run_conv(h, h->fus1, b.f108, nullptr, b.f72a, S, 6, 6, true, false, s))) return rc;
+  if ((rc = run_conv(h, h->fus2, b.f72a, nullptr, b.f72b, S, 6, 6, false, false, s))) return rc;
+  HIPCHK(h, ut::launch_ftl_out_temporal_in(a, b, s));
+  if ((rc = run_conv(h, h->tmp[0], b.t92a, nullptr, b.t92b, S, 6, 6, true, false, s))) return rc;
+  if ((rc = run_conv(h, h->tmp[1], b.t92b, nullptr, b.t92a, S, 6, 6, true, false, s))) return rc;
+  if ((rc = run_conv(h, h->tmp[2], b.t92a, nullptr, b.t92b, S, 6, 6, false, false, s))) return rc;
+  const Regressor& reg = mode == UT_MODE_KNOWN_SKELETON ? h->reg_k : h->reg_u;
+  if (mode == UT_MODE_KNOWN_SKELETON)
+    HIPCHK(h, ut::launch_skeleton(skel, h->skel_w, h->skel_b, h->skel_scale, h->skel_shift, b.skel, n_skel, s));
+  HIPCHK(h, ut::launch_temporal_out(a, b.t92b, b.skel, n_skel, b.regin, reg.c, s));
+  // two BasicBlocks on the 6x6 map (lib/models/model_utils.py:195-208)
+  if ((rc = run_block(h, reg.blocks[0], b.regin, b.rega, nullptr, b.regb, S, 6, 6, s))) return rc;
+  if ((rc = run_block(h, reg.blocks[1], b.regb, b.rega, nullptr, b.regin, S, 6, 6, s))) return rc;
+  HIPCHK(h, ut::launch_pool_decode(a, b.regin, reg.c, reg.w_out, reg.b_out, reg.d, out_pose, out_raw, s));
+  return UT_OK;
+}
+
+int ut_reset_memory(ut_handle h) {
+  if (!h) return UT_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipDeviceSynchronize());
+  if (h->slots_cap) {
+    HIPCHK(h, hipMemset(h->mem, 0, (size_t)h->slots_cap * 36 * 18 * sizeof(float)));
+    HIPCHK(h, hipMemset(h->prev_ext, 0, (size_t)h->slots_cap * 16 * sizeof(float)));
+  }
+  h->slots_used = 0;
+  return UT_OK;
+}
+
+int ut_get_memory(ut_handle h, float* mem, float* prev_ext, int max_slots, void* stream) {
+  if (!h) return UT_E_INVALID;
+  int n = h->slots_used < max_slots ? h->slots_used : max_slots;
+  if (n > 0) {
+    if (!mem || !prev_ext) return fail(h, UT_E_INVALID, "ut_get_memory: null output");
+    HIPCHK(h, ut::launch_mem_export(h->mem, mem, n, (hipStream_t)stream));
+    HIPCHK(h, hipMemcpyAsync(prev_ext, h->prev_ext, (size_t)n * 16 * sizeof(float), hipMemcpyDeviceToDevice,
+                             (hipStream_t)stream));
+  }
+  return h->slots_used;
+}
+
+int ut_fk(ut_handle h, const float* hand_model, int n_models, const float* joint_angles, int ja_stride,
+          const float* wrist_xf, int xf_stride, const int64_t* mirror, float t_scale, int n, float* out, void* stream) {
+  // stateless: h may be NULL (errors then land in the thread-local slot read by ut_last_error(NULL))
+  if (n == 0) return UT_OK;
+  if (!hand_model || !joint_angles || !wrist_xf || !out || n < 0 || (n_models != 1 && n_models != n) ||
+      ja_stride < 22 || xf_stride < 16)
+    return fail(h, UT_E_INVALID, "ut_fk: bad argument");
+  HIPCHK(h, ut::launch_fk(hand_model, n_models, joint_angles, ja_stride, wrist_xf, xf_stride, mirror, t_scale, n, out,
+                          (hipStream_t)stream));
+  return UT_OK;
+}
+
+int ut_profile_begin(ut_handle h, void* stream) {
+  if (!h) return UT_E_INVALID;
+  (void)stream;
+  for (auto& pe : h->prof) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+  h->prof.clear();
+  h->profiling = true;
+  return UT_OK;
+}
+
+int ut_profile_end(ut_handle h, void* stream, double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total) {
+  if (!h) return UT_E_INVALID;
+  h->profiling = false;
+  HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+  double ms = 0, fl = 0;
+  for (auto& pe : h->prof) {
+    float t = 0;
+    HIPCHK(h, hipEventElapsedTime(&t, pe.a, pe.b));
+    ms += t; fl += pe.flops;
+  }
+  if (conv_ms_total) *conv_ms_total = ms;
+  if (conv_launches) *conv_launches = (int64_t)h->prof.size();
+  if (conv_flops_total) *conv_flops_total = fl;
+  for (auto& pe : h->prof) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+  h->prof.clear();
+  return UT_OK;
+}
+
+}  // extern "C"

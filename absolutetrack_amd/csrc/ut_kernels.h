@@ -1,0 +1,85 @@
+// Internal launch interface between the host orchestration (ut_api.cpp) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ut {
+
+// One convolution (1x1 or 3x3, stride 1 or 2) as an implicit GEMM over NHWC activations:
+//   out[m][n] = act( sum_k A[m][k] * Wp[n][k] + bias[n] (+ res[m][n]) ),  m = (img, oy, ox)
+// k is ordered (tap, cin); Wp is [cout_pad][k_pad] k-contiguous, zero padded, BatchNorm folded.
+struct ConvLaunch {
+  const float* in;     // [n_img, H, W, cin]          (cin % 4 == 0)
+  const float* w;      // [cout_pad][k_pad]
+  const float* bias;   // [cout_pad]
+  const float* res;    // optional residual, same layout as out
+  float* out;          // NHWC [n_img, Ho, Wo, cout_store] or NCHW [n_img, cout_store, Ho*Wo]
+  int n_img, H, W, cin, Ho, Wo;
+  int cout_store;      // channels written per pixel (== channel stride of out / res)
+  int cout_pad;        // rows of Wp (multiple of 128)
+  int k_total;         // taps * cin
+  int k_pad;           // row stride of Wp (multiple of 32)
+  int ksize, stride, pad;
+  int relu;
+  int out_nchw;
+};
+
+hipError_t launch_conv_igemm(const ConvLaunch& c, hipStream_t s);
+
+// stem: conv3x3(1->32,pad 1)+BN+ReLU+maxpool2 ; crops [n,96,96] -> NHWC [n,48,48,32]
+hipError_t launch_stem(const float* crops, const float* w /*[32][9]*/, const float* bias /*[32]*/,
+                       float* out, int n, hipStream_t s);
+
+struct HeadBuffers {
+  // workspace, all NHWC over the 6x6 map: [S,36,C]
+  float* cat144;    // [S,36,144] canonical-space features of both views
+  float* f108;      // [S,36,108]
+  float* f72a;      // [S,36,72]
+  float* f72b;      // [S,36,72] fusion output (canonical space)
+  float* fused;     // [S,36,72] cam0-space fused features (input of the temporal block)
+  float* t92a;      // [S,36,92] temporal ping
+  float* t92b;      // [S,36,92] temporal pong
+  float* regin;     // [S,36,C] regressor input (C = 76 or 72)
+  float* rega;      // [S,36,C]
+  float* regb;      // [S,36,C]
+  float* skel;      // [n_skel,36,4]
+  float* xf;        // [S,40] per-sample transforms: A0(12) A1(12) s0(1) rel(12) flags
+};
+
+struct HeadArgs {
+  const float* feat;        // [N,72,36] NCHW
+  const float* intrinsics;  // [N,3,3]
+  const float* extrinsics;  // [N,4,4]
+  const int64_t* sample_range;
+  const int64_t* memory_idx;
+  const uint8_t* use_memory;
+  const int64_t* hand_idx;
+  int n_samples;
+  float* mem;               // [slots,36,18] NHWC temporal memory
+  float* prev_ext;          // [slots,16]
+};
+
+hipError_t launch_ftl_in(const HeadArgs& a, const HeadBuffers& b, hipStream_t s);
+hipError_t launch_ftl_out_temporal_in(const HeadArgs& a, const HeadBuffers& b, hipStream_t s);
+hipError_t launch_temporal_out(const HeadArgs& a, const float* t_out /*[S,36,92]*/, const float* skel,
+                               int n_skel, float* regin, int reg_c, hipStream_t s);
+hipError_t launch_skeleton(const float* skel_in /*[n_skel,2,22,3]*/, const float* w /*[144][132]*/,
+                           const float* bias /*[144]*/, const float* bn_scale /*[4]*/,
+                           const float* bn_shift /*[4]*/, float* out /*[n_skel,36,4]*/, int n_skel,
+                           hipStream_t s);
+// avgpool(6x6) -> 1x1 conv (C->D) -> decode -> world transform -> pose record [S,60]
+hipError_t launch_pool_decode(const HeadArgs& a, const float* reg_feat /*[S,36,C]*/, int reg_c,
+                              const float* w /*[D][C]*/, const float* bias /*[D]*/, int d,
+                              float* out_pose, float* out_raw, hipStream_t s);
+
+hipError_t launch_fk(const float* hand_model, int n_models, const float* ja, int ja_stride,
+                     const float* xf, int xf_stride, const int64_t* mirror, float t_scale, int n,
+                     float* out, hipStream_t s);
+
+hipError_t launch_mem_export(const float* mem /*[slots,36,18]*/, float* out /*[slots,18,36]*/, int slots, hipStream_t s);
+
+hipError_t launch_warp(const uint8_t* src, int n_src, int src_h, int src_w, const double* cam,
+                       const double* crop, const int32_t* src_index, int n_crops, int mode, float* out,
+                       hipStream_t s);
+
+}  // namespace ut

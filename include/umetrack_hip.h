@@ -1,0 +1,137 @@
+/* libumetrack_hip.so - C ABI of the MI355X-native UmeTrack per-frame inference hot path.
+ *
+ * The reference (2InfinityN6eyond/AbsoluteTrack) is pure Python: it has no FFI.  Each entry
+ * point below replaces the Python/ATen/OpenCV code cited next to it; INTEGRATION.md shows the
+ * ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every data pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm tensors), fp32
+ *    unless stated; index tensors are int64 like the reference's; the library owns only its
+ *    handle, its packed weights, its activation workspace and the temporal-memory state.
+ *  - every compute entry takes the hipStream_t to enqueue on (passed as void*); nothing
+ *    synchronises the device except ut_create/ut_reserve/ut_destroy.
+ *  - return value: 0 = ok, negative = error (UT_E_*); ut_last_error() gives the message.
+ *  - a handle is bound to one device and is not thread-safe; distinct handles are independent
+ *    (the reference runs one model per process, run_eval_known_skeleton.py:117-119).
+ */
+#ifndef UMETRACK_HIP_H
+#define UMETRACK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ut_context* ut_handle;
+
+enum {
+  UT_OK = 0,
+  UT_E_INVALID = -1,   /* bad argument / shape */
+  UT_E_HIP = -2,       /* a HIP runtime call failed */
+  UT_E_WEIGHTS = -3,   /* weight blob has the wrong size */
+  UT_E_UNSUPPORTED = -4
+};
+
+enum { UT_MODE_KNOWN_SKELETON = 0, UT_MODE_UNKNOWN_SKELETON = 1 };
+enum { UT_REMAP_CV2_FIXED = 0, UT_REMAP_FLOAT = 1 };
+
+#define UT_CROP 96
+#define UT_FEAT_CH 72
+#define UT_FEAT_PIX 36
+#define UT_POSE_REC 60        /* 22 joint angles | 16 wrist xf (row major, metres) | 1 scale | 21 sigmas */
+#define UT_CAM_PARAMS 32      /* per source camera, doubles: see ut_warp_crops */
+#define UT_CROP_PARAMS 24     /* per crop camera, doubles */
+#define UT_HAND_MODEL_FLOATS 321
+#define UT_WEIGHT_BLOB_FLOATS 4259410
+
+/* Number of floats ut_create expects: the reference state_dict (lib/models/model_loader.py:84-87)
+ * flattened in its own key order, every tensor as fp32 (num_batches_tracked as one float). */
+size_t ut_weight_blob_floats(void);
+
+/* lib/models/model_loader.py:53-88 (load_pretrained_model) + UmeTrackModel.to(device).
+ * weights_blob is a HOST pointer.  BatchNorm is folded and the weights are packed for the
+ * kernels here, once. */
+int ut_create(int device, const float* weights_blob, size_t n_floats, ut_handle* out);
+int ut_destroy(ut_handle h);
+const char* ut_last_error(ut_handle h);   /* h may be NULL: error of the last failed ut_create */
+
+/* Pre-size the activation workspace / temporal state so that later calls never allocate
+ * (needed before capturing calls into a hipGraph). */
+int ut_reserve(ut_handle h, int max_crops, int max_samples, int max_slots);
+
+/* Crops processed per backbone pass (activations of one pass stay resident in L2/Infinity
+ * Cache).  0 = library default. */
+int ut_set_backbone_chunk(ut_handle h, int crops_per_pass);
+
+/* lib/tracker/tracker.py:61-89 (_warp_image) + :332 (/255) for a batch of crops.
+ *  src          u8 [n_src_images, src_h, src_w]
+ *  cam_params   f64 [n_src_images, 32]: fx fy cx cy | k1 k2 k3 k4 p1 p2 k5 k6 | R(9, row major) t(3)
+ *               of camera_to_world | 8 unused           (lib/common/camera.py:109-143,296-312)
+ *  crop_params  f64 [n_crops, 24]: fx fy cx cy | R(9) t(3) of the crop camera_to_world | 8 unused
+ *               (lib/common/camera.py:61-75,320-329)
+ *  src_index    i32 [n_crops] which source image each crop samples
+ *  out          f32 [n_crops, 96, 96] in [0,1]
+ *  (stateless: h may be NULL)
+ *  remap_mode   UT_REMAP_CV2_FIXED: OpenCV's 8-bit INTER_LINEAR arithmetic (coordinates to 1/32
+ *               px, 15-bit weights, rounded u8) then /255;  UT_REMAP_FLOAT: exact float bilinear. */
+int ut_warp_crops(ut_handle h, const uint8_t* src, int n_src_images, int src_h, int src_w,
+                  const double* cam_params, const double* crop_params, const int32_t* src_index,
+                  int n_crops, int remap_mode, float* out, void* stream);
+
+/* FeatureExtractor._image_backbone: lib/models/model_utils.py:107-138,
+ * lib/models/backbone_resnet.py:14-192, called at lib/models/umetrack_model.py:127-129.
+ *  crops f32 [n_crops,96,96] -> feat f32 [n_crops,72,6,6] (NCHW like the reference). */
+int ut_backbone(ut_handle h, const float* crops, int n_crops, float* feat, void* stream);
+
+/* Everything after the backbone in UmeTrackModel.regress_pose_use_skeleton /
+ * regress_pose_pred_skel_scale (lib/models/umetrack_model.py:131-242): single-view xfs, FTL,
+ * 2-view fusion, temporal ConvRNN (state kept in the handle, lib/models/temporal.py:93-139),
+ * skeleton encoder, pose regressor, decoders (lib/models/regressor.py:76-121,163-186),
+ * Procrustes (lib/models/model_utils.py:17-54) and the world transform (:77-90).
+ *  feat [n_crops,72,6,6]; intrinsics [n_crops,3,3]; extrinsics [n_crops,4,4];
+ *  sample_range i64 [n_samples,2] (1 or 2 views per sample); memory_idx i64 [n_samples]
+ *  (distinct slots, all < n_slots); use_memory u8 [n_samples]; hand_idx i64 [n_samples];
+ *  skel f32 [n_skel,2,22,3] = (joint_rotation_axes, joint_rest_positions[m]) with n_skel in
+ *  {1, n_samples}, NULL in UT_MODE_UNKNOWN_SKELETON (single-view samples are then rejected on
+ *  the host when `all_multiview` is 0);
+ *  n_slots = max(memory_idx)+1 as computed by the caller (lib/models/temporal.py:102);
+ *  out_pose f32 [n_samples,60]; out_raw (optional, may be NULL) f32 [n_samples,64] regressor
+ *  output before decoding. */
+int ut_fuse_temporal_regress(ut_handle h, const float* feat, const float* intrinsics,
+                             const float* extrinsics, const int64_t* sample_range,
+                             const int64_t* memory_idx, const uint8_t* use_memory,
+                             const int64_t* hand_idx, int n_crops, int n_samples, int n_slots,
+                             int all_multiview, const float* skel, int n_skel, int mode,
+                             float* out_pose, float* out_raw, void* stream);
+
+/* Drop the temporal state (a fresh SimpleConvRNN, lib/models/temporal.py:40-41). */
+int ut_reset_memory(ut_handle h);
+/* Copy out the state for inspection: mem f32 [n_slots,18,6,6] (NCHW), prev_ext f32 [n_slots,4,4];
+ * returns the number of slots currently held (<= max_slots copied). */
+int ut_get_memory(ut_handle h, float* mem, float* prev_ext, int max_slots, void* stream);
+
+/* lib/common/hand_skinning.py:189-209 (skin_landmarks) for a batch of poses.
+ *  hand_model f32 [n_models, 321]: axes[22,3] rest[22,3] landmark_rest[21,3] bone_weights[21,3]
+ *             bone_indices[21,3] (as floats); n_models in {1, n}
+ *  joint_angles [n,22]; wrist_xf [n,4,4] with row strides given in floats (so that the pose
+ *  record of ut_fuse_temporal_regress can be consumed in place); translation is multiplied by
+ *  t_scale (1000 for metres->mm, lib/tracker/tracker.py:379) and column 0 is negated where
+ *  mirror[i] != 0 (lib/tracker/perspective_crop.py:48-49; mirror may be NULL);
+ *  out [n,21,3].  Stateless: h may be NULL. */
+int ut_fk(ut_handle h, const float* hand_model, int n_models, const float* joint_angles,
+          int ja_stride, const float* wrist_xf, int xf_stride, const int64_t* mirror, float t_scale,
+          int n, float* out, void* stream);
+
+/* Names of the kernels launched by the calls above and the average duration in ms of the
+ * dominant (implicit-GEMM convolution) kernel measured with hipEvents on `stream` between
+ * ut_profile_begin and ut_profile_end (bench.py roofline leg). */
+int ut_profile_begin(ut_handle h, void* stream);
+int ut_profile_end(ut_handle h, void* stream, double* conv_ms_total, int64_t* conv_launches,
+                   double* conv_flops_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
