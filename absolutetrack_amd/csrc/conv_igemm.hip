@@ -20,6 +20,7 @@
 namespace ut {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
 constexpr int LDS_ROW = BK + 4;   // floats; 144 B row stride = 9 x 16 B -> conflict-free b128 reads
@@ -47,63 +48,66 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvLaunch p) {
   const int n0 = blockIdx.y * BN;
 
   // ---- per-thread im2col row bookkeeping (fixed over the K loop)
-  const float* a_base[AP];
+  // Activations and weights are read through raw buffer descriptors: a tap that falls outside the
+  // image (or a row beyond M) gets an out-of-range offset and the hardware returns zeros - no
+  // branches and no selects on the load path, so the loads stay in flight under the MFMAs.
+  // k beyond taps*cin needs no masking: the packed weights are zero there and every address that
+  // passes the bounds test holds a finite activation.
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.in), 0, (int)((size_t)p.n_img * p.H * p.W * p.cin * sizeof(float)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.w), 0, (int)((size_t)p.cout_pad * p.k_pad * sizeof(float)), 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  int a_pix[AP];                 // element offset of the (iy0, ix0) pixel of this row (may be "negative")
   int a_iy[AP], a_ix[AP];
-  bool a_ok[AP];
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
     int m = m0 + r0 + 32 * i;
-    a_ok[i] = m < M;
-    int mm = a_ok[i] ? m : 0;
+    bool ok = m < M;
+    int mm = ok ? m : 0;
     int img = mm / (p.Ho * p.Wo);
     int rem = mm - img * (p.Ho * p.Wo);
     int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-    a_iy[i] = oy * p.stride - p.pad;
+    a_iy[i] = ok ? oy * p.stride - p.pad : -100000;   // rows beyond M never pass the bounds test
     a_ix[i] = ox * p.stride - p.pad;
-    a_base[i] = p.in + (size_t)img * p.H * p.W * p.cin;
+    a_pix[i] = ((img * p.H + a_iy[i]) * p.W + a_ix[i]) * p.cin;
   }
-  const float* b_ptr = p.w + (size_t)(n0 + r0) * p.k_pad + 4 * g;
+  unsigned b_off = (unsigned)(((n0 + r0) * p.k_pad + 4 * g) * 4);
+  const unsigned b_row_step = (unsigned)(32 * p.k_pad * 4);
 
-  // (tap, channel) of this thread's 4-float group, advanced by 32 per chunk
-  int kc = 4 * g;              // k index of the group in the current chunk
-  int tap = kc / p.cin;
-  int ch = kc - tap * p.cin;
+  // (tap, channel) of this thread's 4-float group; cin >= 32 so one step of 32 crosses at most one tap
+  int tap = (4 * g) / p.cin;
+  int ch = 4 * g - tap * p.cin;
 
-  float4 a_reg[AP], b_reg[BP];
+  u32x4 a_reg[AP], b_reg[BP];
 
-  auto fetch = [&](int chunk) {
-    (void)chunk;
-    int dy = 0, dx = 0;
-    if (p.ksize == 3) { dy = tap / 3; dx = tap - 3 * dy; }
-    const bool k_ok = kc < p.k_total;
-#pragma unroll
-    for (int i = 0; i < AP; ++i) {
-      int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
-      bool ok = a_ok[i] && k_ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) v = *reinterpret_cast<const float4*>(a_base[i] + ((size_t)(iy * p.W + ix) * p.cin + ch));
-      a_reg[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < BP; ++i)
-      b_reg[i] = *reinterpret_cast<const float4*>(b_ptr + (size_t)(32 * i) * p.k_pad);
-    // advance to the next chunk
-    b_ptr += BK;
-    kc += BK;
-    ch += BK;
-    while (ch >= p.cin) { ch -= p.cin; ++tap; }
-  };
+#define UT_FETCH()                                                                                   \
+  {                                                                                                  \
+    int dy = 0, dx = 0;                                                                              \
+    if (p.ksize == 3) { dy = (tap * 11) >> 5; dx = tap - 3 * dy; } /* tap/3 for tap < 32 */         \
+    const int tap_off = (dy * p.W + dx) * p.cin + ch;                                                \
+    _Pragma("unroll") for (int i = 0; i < AP; ++i) {                                                 \
+      const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;                                                \
+      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;                  \
+      const unsigned off = ok ? (unsigned)(a_pix[i] + tap_off) * 4u : OOB;                           \
+      a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off, 0, 0);                           \
+    }                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < BP; ++i)                                                   \
+      b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off + i * b_row_step, 0, 0);        \
+    b_off += BK * 4;                                                                                 \
+    ch += BK;                                                                                        \
+    if (ch >= p.cin) { ch -= p.cin; ++tap; }                                                         \
+  }
 
-  auto stage = [&](int buf) {
-    float* as = smem + buf * STAGE;
-    float* bs = as + BM * LDS_ROW;
-#pragma unroll
-    for (int i = 0; i < AP; ++i)
-      *reinterpret_cast<float4*>(as + (r0 + 32 * i) * LDS_ROW + 4 * g) = a_reg[i];
-#pragma unroll
-    for (int i = 0; i < BP; ++i)
-      *reinterpret_cast<float4*>(bs + (r0 + 32 * i) * LDS_ROW + 4 * g) = b_reg[i];
-  };
+#define UT_STAGE(buf)                                                                                \
+  {                                                                                                  \
+    float* as_ = smem + (buf) * STAGE;                                                               \
+    float* bs_ = as_ + BM * LDS_ROW;                                                                 \
+    _Pragma("unroll") for (int i = 0; i < AP; ++i)                                                   \
+      *reinterpret_cast<u32x4*>(as_ + (r0 + 32 * i) * LDS_ROW + 4 * g) = a_reg[i];                   \
+    _Pragma("unroll") for (int i = 0; i < BP; ++i)                                                   \
+      *reinterpret_cast<u32x4*>(bs_ + (r0 + 32 * i) * LDS_ROW + 4 * g) = b_reg[i];                   \
+  }
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -117,13 +121,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvLaunch p) {
   const int fr = lane & 31;          // fragment row
   const int fh = lane >> 5;          // k half
 
-  fetch(0);
-  stage(0);
+  UT_FETCH();
+  UT_STAGE(0);
   __syncthreads();
 
   for (int c = 0; c < n_chunks; ++c) {
     const int buf = c & 1;
-    if (c + 1 < n_chunks) fetch(c + 1);
+    if (c + 1 < n_chunks) UT_FETCH();
     const float* as = smem + buf * STAGE + (wm * (MI * 32) + fr) * LDS_ROW + 4 * fh;
     const float* bs = smem + buf * STAGE + BM * LDS_ROW + (wn * (NI * 32) + fr) * LDS_ROW + 4 * fh;
 #pragma unroll
@@ -143,9 +147,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvLaunch p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
         }
     }
-    if (c + 1 < n_chunks) stage(buf ^ 1);
+    if (c + 1 < n_chunks) UT_STAGE(buf ^ 1);
     __syncthreads();
   }
+#undef UT_FETCH
+#undef UT_STAGE
 
   // ---- epilogue
   const int hw = p.Ho * p.Wo;
@@ -194,7 +200,10 @@ static hipError_t launch_cfg(const ConvLaunch& c, hipStream_t s) {
 }
 
 hipError_t launch_conv_igemm(const ConvLaunch& c, hipStream_t s) {
-  if (c.cin % 4 != 0 || c.k_pad % BK != 0 || c.cout_pad % 128 != 0) return hipErrorInvalidValue;
+  if (c.cin % 4 != 0 || c.cin < BK || c.k_pad % BK != 0 || c.cout_pad % 128 != 0 || c.ksize * c.ksize > 9)
+    return hipErrorInvalidValue;
+  // 32-bit byte offsets into the activation tensor
+  if ((size_t)c.n_img * c.H * c.W * c.cin * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
   if (c.cout_store <= 32) return launch_cfg<128, 32, 4, 1>(c, s);
   if (c.cout_store <= 64) return launch_cfg<128, 64, 2, 2>(c, s);
   return launch_cfg<128, 128, 2, 2>(c, s);

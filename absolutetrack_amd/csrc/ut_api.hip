@@ -50,10 +50,14 @@ struct ut_context {
   ConvW proj, fus0, fus1, fus2, tmp[3];
   float *skel_w = nullptr, *skel_b = nullptr, *skel_scale = nullptr, *skel_shift = nullptr;
   Regressor reg_k, reg_u;
-  // backbone workspace (per pass of `chunk` crops)
-  int chunk = 256;
-  int ws_crops = 0;
+  // backbone workspace.  Phase A (stem, layer1, layer2) runs in passes of `chunk` crops so that its
+  // large activations stay cache resident; phase B (layer3, layer4, projection) runs over up to
+  // PHASE_B_MAX crops at once so that the small late maps still fill the chip with workgroups.
+  int chunk = 512;
+  int ws_crops = 0;       // phase-A capacity (crops)
   float *bufX = nullptr, *bufH = nullptr, *bufY = nullptr, *bufD = nullptr;
+  int wsb_crops = 0;      // phase-B capacity (crops)
+  float *bufL2 = nullptr, *bufP = nullptr, *bufQ = nullptr, *bufBH = nullptr, *bufBD = nullptr;
   // head workspace
   int ws_samples = 0;
   ut::HeadBuffers hb{};
@@ -198,6 +202,23 @@ int ensure_backbone_ws(ut_handle h, int crops) {
       (rc = dev_alloc(h, &h->bufY, big)) || (rc = dev_alloc(h, &h->bufD, small)))
     return rc;
   h->ws_crops = crops;
+  return UT_OK;
+}
+
+constexpr int PHASE_B_MAX = 16384;
+
+int ensure_phase_b_ws(ut_handle h, int crops) {
+  if (crops <= h->wsb_crops) return UT_OK;
+  HIPCHK(h, hipDeviceSynchronize());
+  float** ptrs[] = {&h->bufL2, &h->bufP, &h->bufQ, &h->bufBH, &h->bufBD};
+  for (auto pp : ptrs) { dev_free(h, *pp); *pp = nullptr; }
+  h->wsb_crops = 0;
+  const size_t l2 = (size_t)crops * 24 * 24 * 64, l3 = (size_t)crops * 12 * 12 * 128;
+  int rc;
+  if ((rc = dev_alloc(h, &h->bufL2, l2)) || (rc = dev_alloc(h, &h->bufP, l3)) || (rc = dev_alloc(h, &h->bufQ, l3)) ||
+      (rc = dev_alloc(h, &h->bufBH, l3)) || (rc = dev_alloc(h, &h->bufBD, l3)))
+    return rc;
+  h->wsb_crops = crops;
   return UT_OK;
 }
 
@@ -382,7 +403,7 @@ int ut_destroy(ut_handle h) {
 
 int ut_set_backbone_chunk(ut_handle h, int crops_per_pass) {
   if (!h || crops_per_pass < 0) return fail(h, UT_E_INVALID, "ut_set_backbone_chunk: bad argument");
-  h->chunk = crops_per_pass == 0 ? 256 : crops_per_pass;
+  h->chunk = crops_per_pass == 0 ? 512 : crops_per_pass;
   return UT_OK;
 }
 
@@ -392,6 +413,8 @@ int ut_reserve(ut_handle h, int max_crops, int max_samples, int max_slots) {
   int rc;
   int c = max_crops < h->chunk ? max_crops : h->chunk;
   if (c > 0 && (rc = ensure_backbone_ws(h, c))) return rc;
+  int cb = max_crops < PHASE_B_MAX ? max_crops : PHASE_B_MAX;
+  if (cb > 0 && (rc = ensure_phase_b_ws(h, cb))) return rc;
   if (max_samples > 0 && (rc = ensure_head_ws(h, max_samples, max_samples))) return rc;
   if (max_slots > 0 && (rc = ensure_slots(h, max_slots, 0))) return rc;
   return UT_OK;
@@ -418,18 +441,35 @@ int ut_backbone(ut_handle h, const float* crops, int n_crops, float* feat, void*
   int rc;
   const int chunk = n_crops < h->chunk ? n_crops : h->chunk;
   if ((rc = ensure_backbone_ws(h, chunk))) return rc;
-  for (int done = 0; done < n_crops; done += chunk) {
-    const int n = n_crops - done < chunk ? n_crops - done : chunk;
-    HIPCHK(h, ut::launch_stem(crops + (size_t)done * 96 * 96, h->stem_w, h->stem_b, h->bufX, n, s));
-    float *x = h->bufX, *y = h->bufY;
-    int hw = 48;
-    for (int b = 0; b < 12; ++b) {
-      if ((rc = run_block(h, h->bb[b], x, h->bufH, h->bufD, y, n, hw, hw, s))) return rc;
+  const int pass_b = n_crops < PHASE_B_MAX ? n_crops : PHASE_B_MAX;
+  if ((rc = ensure_phase_b_ws(h, pass_b))) return rc;
+  for (int base = 0; base < n_crops; base += pass_b) {
+    const int nb = n_crops - base < pass_b ? n_crops - base : pass_b;
+    // ---- phase A: stem + layer1 (48x48x32) + layer2 (24x24x64), `chunk` crops per pass
+    for (int done = 0; done < nb; done += chunk) {
+      const int n = nb - done < chunk ? nb - done : chunk;
+      HIPCHK(h, ut::launch_stem(crops + (size_t)(base + done) * 96 * 96, h->stem_w, h->stem_b, h->bufX, n, s));
+      float *x = h->bufX, *y = h->bufY;
+      int hw = 48;
+      for (int b = 0; b < 5; ++b) {
+        float* dst = b == 4 ? h->bufL2 + (size_t)done * 24 * 24 * 64 : y;
+        if ((rc = run_block(h, h->bb[b], x, h->bufH, h->bufD, dst, n, hw, hw, s))) return rc;
+        hw = (hw + 2 - 3) / h->bb[b].conv1.stride + 1;
+        float* t = x; x = y; y = t;
+      }
+    }
+    // ---- phase B: layer3 (12x12x128) + layer4 (6x6x256) + projection over the whole pass
+    const float* x = h->bufL2;
+    float *y = h->bufP, *other = h->bufQ;
+    int hw = 24;
+    for (int b = 5; b < 12; ++b) {
+      if ((rc = run_block(h, h->bb[b], x, h->bufBH, h->bufBD, y, nb, hw, hw, s))) return rc;
       hw = (hw + 2 - 3) / h->bb[b].conv1.stride + 1;
-      float* t = x; x = y; y = t;
+      x = y;
+      float* t = y; y = other; other = t;
     }
     // projection 256 -> 72, written NCHW like the reference (lib/models/model_utils.py:134)
-    if ((rc = run_conv(h, h->proj, x, nullptr, feat + (size_t)done * 72 * 36, n, 6, 6, false, true, s))) return rc;
+    if ((rc = run_conv(h, h->proj, x, nullptr, feat + (size_t)base * 72 * 36, nb, 6, 6, false, true, s))) return rc;
   }
   return UT_OK;
 }

@@ -1,0 +1,221 @@
+"""Batched hot path: many independent frames per launch sequence, sharded across GPUs.
+
+The reference drives the path one frame at a time (run_eval_known_skeleton.py:68-89) and its only
+parallelism is one process per recording (`Pool(8)`, :117-119).  Frames are independent, so the
+MI355X-native shape of the same computation is: stack the frames of a shard on one GPU, run each
+stage ONCE over the whole stack (resample -> backbone -> fuse/temporal/regress -> FK), and shard
+contiguous frame blocks across the ranks of a node with a single all-gather of the packed per-hand
+records at the end (SURVEY.md section 8 e).  No collective sits inside the data path.
+
+record layout (fp32, 123 per hand-frame): pose record [60] (ut_fuse_temporal_regress) | 21x3 keypoints (mm)
+"""
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _native, arch, geometry
+from .hand import HandModel
+from .tracker import (HandTrackerOpts, MAX_VIEW_NUM, SingleHandPose, gen_crop_cameras_from_pose,
+                      network_camera_inputs)
+
+RECORD = arch.POSE_REC + arch.N_LANDMARKS * 3
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "recording_00_labels.npz")
+_CAM_FIELDS = ("ImageSizeX", "ImageSizeY", "fx", "fy", "cx", "cy", "k1", "k2", "k3", "k4", "p1", "p2", "k5", "k6")
+
+
+# ----------------------------------------------------------------------------- label data
+def load_labels(path: str = _DATA) -> Dict[str, np.ndarray]:
+    """sample_data/recording_00.json of the reference as arrays (written by oracle/gen_goldens.py)."""
+    return dict(np.load(path))
+
+
+def hand_model_from_labels(lab: Dict[str, np.ndarray]) -> HandModel:
+    t = {k[3:]: torch.from_numpy(v) for k, v in lab.items() if k.startswith("hm.")}
+    z = torch.zeros(22)
+    return HandModel(joint_rotation_axes=t["joint_rotation_axes"], joint_rest_positions=t["joint_rest_positions"],
+                     joint_frame_index=z, joint_parent=z, joint_first_child=z, joint_next_sibling=z,
+                     landmark_rest_positions=t["landmark_rest_positions"],
+                     landmark_rest_bone_weights=t["landmark_rest_bone_weights"],
+                     landmark_rest_bone_indices=t["landmark_rest_bone_indices"], hand_scale=None,
+                     joint_limits=t["joint_limits"])
+
+
+def cameras_for_frame(lab: Dict[str, np.ndarray], frame: int) -> List[geometry.Fisheye62CameraModel]:
+    cams = []
+    for ci in range(lab["cameras"].shape[0]):
+        js = dict(zip(_CAM_FIELDS, lab["cameras"][ci]))
+        js["DistortionModel"] = "FishEye62"
+        js["ImageSizeX"], js["ImageSizeY"] = int(js["ImageSizeX"]), int(js["ImageSizeY"])
+        cams.append(geometry.read_camera_from_json(js).copy(camera_to_world_xf=lab["camera_to_world_transforms"][frame, ci]))
+    return cams
+
+
+# ----------------------------------------------------------------------------- batch description
+@dataclass
+class FrameBatch:
+    """Device-resident inputs of one pass over F frames (S hand-samples, N crops)."""
+    src: torch.Tensor            # u8  [F*C, H, W]
+    cam_params: torch.Tensor     # f64 [F*C, 32]
+    crop_params: torch.Tensor    # f64 [N, 24]
+    src_index: torch.Tensor      # i32 [N]
+    intrinsics: torch.Tensor     # f32 [N,3,3]
+    extrinsics: torch.Tensor     # f32 [N,4,4]
+    sample_range: torch.Tensor   # i64 [S,2]
+    memory_idx: torch.Tensor     # i64 [S]
+    use_memory: torch.Tensor     # u8  [S]
+    hand_idx: torch.Tensor       # i64 [S]
+    n_slots: int
+    all_multiview: bool
+
+    @property
+    def n_samples(self) -> int:
+        return self.sample_range.shape[0]
+
+    @property
+    def n_crops(self) -> int:
+        return self.crop_params.shape[0]
+
+
+def crop_plan_from_labels(lab: Dict[str, np.ndarray], hand_model: HandModel, frame_ids: Sequence[int],
+                          hands: Sequence[int] = (0, 1), opts: Optional[HandTrackerOpts] = None):
+    """Crop cameras for every (frame, hand) exactly as HandTracker.gen_crop_cameras picks them
+    (lib/tracker/tracker.py:222-260), as flat numpy rows.  Label frames repeat with period len(labels), so
+    the per-label-frame result is computed once and tiled."""
+    opts = opts or HandTrackerOpts()
+    n_lab = lab["joint_angles"].shape[0]
+    cache: Dict[int, list] = {}
+    cam_rows, crop_rows, src_index, intr, extr, ranges, hand_idx = [], [], [], [], [], [], []
+    n_cams = lab["cameras"].shape[0]
+    for f_out, f in enumerate(frame_ids):
+        lf = int(f) % n_lab
+        if lf not in cache:
+            cams = cameras_for_frame(lab, lf)
+            entry = {"cams": [geometry.pack_camera_model(c) for c in cams], "hands": {}}
+            for h in hands:
+                if lab["hand_confidences"][lf, h] < 0.5:
+                    continue
+                pose = SingleHandPose(joint_angles=lab["joint_angles"][lf, h], wrist_xform=lab["wrist_transforms"][lf, h],
+                                      hand_confidence=float(lab["hand_confidences"][lf, h]))
+                cc = gen_crop_cameras_from_pose(cams, lab["camera_angles"], hand_model, pose, h, opts.num_crop_points,
+                                                np.array([arch.CROP, arch.CROP]), max_view_num=MAX_VIEW_NUM,
+                                                sort_camera_index=True, focal_multiplier=opts.hand_ratio_in_crop,
+                                                mirror_right_hand=True,
+                                                min_required_vis_landmarks=opts.min_required_vis_landmarks)
+                if cc:
+                    entry["hands"][h] = [(ci, geometry.pack_camera_model(c), *network_camera_inputs(c)) for ci, c in cc.items()]
+            cache[lf] = entry
+        entry = cache[lf]
+        cam_rows.extend(entry["cams"])
+        for h, views in entry["hands"].items():
+            start = len(crop_rows)
+            for ci, row, k, ext in views:
+                crop_rows.append(row)
+                src_index.append(f_out * n_cams + ci)
+                intr.append(k)
+                extr.append(ext)
+            ranges.append((start, len(crop_rows)))
+            hand_idx.append(h)
+    return {"cam_params": np.stack(cam_rows), "crop_params": np.stack(crop_rows),
+            "src_index": np.asarray(src_index, np.int32), "intrinsics": np.stack(intr).astype(np.float32),
+            "extrinsics": np.stack(extr).astype(np.float32), "sample_range": np.asarray(ranges, np.int64),
+            "hand_idx": np.asarray(hand_idx, np.int64)}
+
+
+def make_batch(plan: dict, src_u8: torch.Tensor, device, independent_frames: bool = True) -> FrameBatch:
+    """independent_frames: every hand-sample owns a temporal slot and starts without memory
+    (`memory_idx=arange(S)`, `use_memory=False`, the throughput configuration of SURVEY.md section 8 d)."""
+    dev = torch.device(device)
+    s = plan["sample_range"].shape[0]
+    sr = plan["sample_range"]
+    return FrameBatch(
+        src=src_u8.to(dev), cam_params=torch.from_numpy(plan["cam_params"]).to(dev),
+        crop_params=torch.from_numpy(plan["crop_params"]).to(dev), src_index=torch.from_numpy(plan["src_index"]).to(dev),
+        intrinsics=torch.from_numpy(plan["intrinsics"]).to(dev), extrinsics=torch.from_numpy(plan["extrinsics"]).to(dev),
+        sample_range=torch.from_numpy(sr).to(dev),
+        memory_idx=torch.arange(s, dtype=torch.long, device=dev) if independent_frames else torch.from_numpy(plan["hand_idx"]).to(dev),
+        use_memory=torch.zeros(s, dtype=torch.uint8, device=dev), hand_idx=torch.from_numpy(plan["hand_idx"]).to(dev),
+        n_slots=s if independent_frames else int(plan["hand_idx"].max()) + 1,
+        all_multiview=bool(((sr[:, 1] - sr[:, 0]) == 2).all()))
+
+
+# ----------------------------------------------------------------------------- the hot path
+class HotPath:
+    """warp -> backbone -> fuse/temporal/regress -> FK over one FrameBatch; all buffers preallocated."""
+
+    def __init__(self, engine: _native.HipEngine, hand_model_mm: HandModel, known_skeleton: bool = True,
+                 remap_mode: int = _native.UT_REMAP_CV2_FIXED):
+        self.engine = engine
+        self.mode = _native.UT_MODE_KNOWN if known_skeleton else _native.UT_MODE_UNKNOWN
+        self.remap_mode = remap_mode
+        dev = engine.device
+        self.hand_blob = torch.from_numpy(_native.hand_model_blob(
+            hand_model_mm.joint_rotation_axes, hand_model_mm.joint_rest_positions, hand_model_mm.landmark_rest_positions,
+            hand_model_mm.landmark_rest_bone_weights, hand_model_mm.landmark_rest_bone_indices)).reshape(1, 321).to(dev)
+        self.skel = None
+        if known_skeleton:   # mm -> m (lib/tracker/tracker.py:361-367)
+            self.skel = torch.stack([hand_model_mm.joint_rotation_axes.float(),
+                                     hand_model_mm.joint_rest_positions.float() * 0.001])[None].contiguous().to(dev)
+        self._bufs = None
+
+    def _buffers(self, b: FrameBatch):
+        key = (b.n_crops, b.n_samples)
+        if self._bufs is None or self._bufs[0] != key:
+            dev = self.engine.device
+            self._bufs = (key, torch.empty(b.n_crops, arch.CROP, arch.CROP, device=dev),
+                          torch.empty(b.n_crops, arch.FEAT_CH, arch.FEAT_HW, arch.FEAT_HW, device=dev),
+                          torch.empty(b.n_samples, RECORD, device=dev))
+            self.engine.reserve(b.n_crops, b.n_samples, b.n_slots)
+        return self._bufs[1:]
+
+    def step(self, b: FrameBatch) -> torch.Tensor:
+        """[S,123] records (pose record | keypoints in mm)."""
+        eng = self.engine
+        crops, feat, rec = self._buffers(b)
+        eng.warp_crops(b.src, b.cam_params, b.crop_params, b.src_index, self.remap_mode, out=crops)
+        eng.backbone(crops, out=feat)
+        s = b.n_samples
+        pose, _ = eng.fuse_temporal_regress(feat, b.intrinsics, b.extrinsics, b.sample_range, b.memory_idx,
+                                            b.use_memory, b.hand_idx, b.n_slots, b.all_multiview, self.skel,
+                                            self.mode, out=self._pose_buf(s))
+        # FK consumes the pose records in place (row stride 60): metres -> mm, right hands un-mirrored
+        kp = eng.fk(self.hand_blob, pose, pose[:, 22:], mirror=b.hand_idx, t_scale=1000.0,
+                    ja_stride=arch.POSE_REC, xf_stride=arch.POSE_REC, n=s, out=self._kp_buf(s))
+        rec[:, : arch.POSE_REC].copy_(pose)
+        rec[:, arch.POSE_REC:].copy_(kp.reshape(s, -1))
+        return rec
+
+    def _pose_buf(self, s):
+        if getattr(self, "_pose", None) is None or self._pose.shape[0] != s:
+            self._pose = torch.empty(s, arch.POSE_REC, device=self.engine.device)
+        return self._pose
+
+    def _kp_buf(self, s):
+        if getattr(self, "_kp", None) is None or self._kp.shape[0] != s:
+            self._kp = torch.empty(s, arch.N_LANDMARKS, 3, device=self.engine.device)
+        return self._kp
+
+
+# ----------------------------------------------------------------------------- sharding
+def shard_frames(n_frames_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of rank `rank`; blocks differ by at most one frame."""
+    base, extra = divmod(n_frames_total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_records(local: torch.Tensor, world: int) -> torch.Tensor:
+    """All-gather equal-sized [S_local, R] record blocks into [world*S_local, R] on every rank
+    (RCCL over xGMI when the process group is 'nccl'; 'gloo' in the CPU tests)."""
+    if world == 1:
+        return local
+    import torch.distributed as dist
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if dist.get_backend() == "gloo":
+        parts = list(out.chunk(world, 0))
+        dist.all_gather(parts, local.contiguous())
+    else:
+        dist.all_gather_into_tensor(out, local.contiguous())
+    return out

@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Headline benchmark: hand-frames/s of the UmeTrack per-frame hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+
+One "step" = one pass of the whole hot path (fisheye->pinhole resample of every crop, backbone,
+fusion/temporal/regressor head, decode, forward kinematics) over one shard of synthetic frames:
+4 fisheye cameras x 2 hands per frame, 2 selected views per hand (BASELINE.json configs[2] shapes;
+cameras / poses / hand model from sample_data/recording_00.json, frame i mod 369; u8 noise images;
+seeded synthetic weights).  Inputs are resident in HBM before the timed region.  Frames shard
+contiguously across ranks (weak scaling: --frames-per-gpu each) and the packed per-hand records are
+all-gathered over RCCL at the end of every step.
+
+Extra JSON objects: `roofline` (the implicit-GEMM convolution kernel, hipEvent-timed per launch in a
+separate profiling pass on the launch stream) and `cpu_baseline` (the CPU oracle's restatement of the
+same path on a bounded sample, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames-per-gpu", type=int, default=1024)
+    ap.add_argument("--mode", choices=["known", "unknown"], default="known")
+    ap.add_argument("--chunk", type=int, default=0, help="crops per backbone pass (0 = library default)")
+    ap.add_argument("--cpu-frames", type=int, default=96, help="label frames timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from absolutetrack_amd import _native, arch, pipeline, synth
+
+    known = args.mode == "known"
+    sd = synth.synthetic_state_dict(0)
+    lab = pipeline.load_labels()
+    hm = pipeline.hand_model_from_labels(lab)
+    eng = _native.HipEngine(sd, device)
+    if args.chunk:
+        eng.set_backbone_chunk(args.chunk)
+
+    f_local = args.frames_per_gpu
+    lo, hi = pipeline.shard_frames(f_local * world, rank, world)
+    plan = pipeline.crop_plan_from_labels(lab, hm, range(lo, hi))
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234 + rank)
+    src = torch.randint(0, 256, (f_local * 4, 480, 636), dtype=torch.uint8, device=device, generator=gen)
+    batch = pipeline.make_batch(plan, src, device)
+    hot = pipeline.HotPath(eng, hm, known_skeleton=known)
+    s_local, n_local = batch.n_samples, batch.n_crops
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def one_step():
+        rec = hot.step(batch)
+        return pipeline.gather_records(rec, world)
+
+    for _ in range(args.warmup):
+        out = one_step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert out.shape == (s_local * world, pipeline.RECORD)
+    finite = bool(torch.isfinite(out).all().item())
+
+    total_hf = s_local * world * args.steps
+    value = total_hf / dt
+    flops_hf = arch.FLOPS_PER_HANDFRAME_KNOWN if known else arch.FLOPS_PER_HANDFRAME_UNKNOWN
+
+    roofline = None
+    if not args.no_roofline:
+        # separate profiling pass: hipEvents around every conv_igemm launch on the launch stream
+        eng.profile_begin()
+        n_prof = 2
+        for _ in range(n_prof):
+            hot.step(batch)
+        ms, launches, flops = eng.profile_end()
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (all instantiations)",
+                    "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": launches // n_prof, "avg_launch_ms": round(ms / max(launches, 1), 5),
+                    "flops_per_launch_avg": flops / max(launches, 1),
+                    "whole_step_tflops": round(value * flops_hf / 1e12, 3)}
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_frames > 0:
+        from oracle import checks
+        # the GPU box gives one GPU a 16-CPU share although os.cpu_count() reports the whole host
+        threads = min(os.cpu_count() or 1, 16)
+        r = checks.time_oracle(sd, args.cpu_frames, threads)
+        cpu = {"value": round(r["hand_frames"] / r["seconds"], 2), "unit": "hand-frames/s", "cores": threads,
+               "kind": "port",
+               "sample": f"{args.cpu_frames} label frames ({r['hand_frames']} hand-frames) of the same workload, "
+                         f"oracle resample+network+FK, {r['seconds']:.1f} s"}
+
+    if rank == 0:
+        line = {
+            "metric": "hand-frames/sec", "value": round(value, 1), "unit": "hand-frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "4 fisheye cameras x 2 hands per frame, 2 views per hand, 96x96 crops, "
+                                   f"{'known' if known else 'unknown'}-skeleton path, full hot path "
+                                   "(resample+backbone+head+FK) + all-gather of records",
+                       "frames_per_gpu": f_local, "hand_frames_per_step": s_local * world,
+                       "crops_per_step": n_local * world, "src_image": "480x636 u8 x 4 cameras",
+                       "parallelism": f"frame-shard x{world}", "outputs_finite": finite},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
