@@ -4,7 +4,8 @@
 // lib/models/backbone_resnet.py:56-72 (BasicBlock), lib/models/model_utils.py:134 (projection),
 // :141-163 (fusion), lib/models/temporal.py:31-38, lib/models/model_utils.py:195-208 (regressor).
 //
-// GEMM view: M = n_img*Ho*Wo output pixels, N = cout, K = taps*cin with k = tap*cin + c.
+// GEMM view: M = n_img*Ho*Wo output pixels, N = cout, K = taps*cin, k ordered (channel slice, tap,
+// channel) - see ut_kernels.h.
 // Activations are NHWC so a k-run of 4 channels is one 16-byte load; weights are pre-packed
 // [cout_pad][k_pad] (k contiguous) with BatchNorm folded in.  A workgroup (4 waves, 256 threads)
 // owns a BM x BN output tile and walks K in chunks of 32:
@@ -75,9 +76,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvLaunch p) {
   unsigned b_off = (unsigned)(((n0 + r0) * p.k_pad + 4 * g) * 4);
   const unsigned b_row_step = (unsigned)(32 * p.k_pad * 4);
 
-  // (tap, channel) of this thread's 4-float group; cin >= 32 so one step of 32 crosses at most one tap
-  int tap = (4 * g) / p.cin;
-  int ch = 4 * g - tap * p.cin;
+  // (slice, tap, channel in slice) of this thread's 4-float group; cslice >= 32, so one step of 32
+  // crosses at most one tap boundary, and taps wrap into the next channel slice
+  const int taps = p.ksize * p.ksize;
+  int tap = (4 * g) / p.cslice;
+  int ch = 4 * g - tap * p.cslice;
+  int ch_base = 0;                // first channel of the current slice
+  if (tap >= taps) { tap -= taps; ch_base = p.cslice; }
 
   u32x4 a_reg[AP], b_reg[BP];
 
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvLaunch p) {
   {                                                                                                  \
     int dy = 0, dx = 0;                                                                              \
     if (p.ksize == 3) { dy = (tap * 11) >> 5; dx = tap - 3 * dy; } /* tap/3 for tap < 32 */         \
-    const int tap_off = (dy * p.W + dx) * p.cin + ch;                                                \
+    const int tap_off = (dy * p.W + dx) * p.cin + ch_base + ch;                                      \
     _Pragma("unroll") for (int i = 0; i < AP; ++i) {                                                 \
       const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;                                                \
       const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;                  \
@@ -96,7 +101,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvLaunch p) {
       b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off + i * b_row_step, 0, 0);        \
     b_off += BK * 4;                                                                                 \
     ch += BK;                                                                                        \
-    if (ch >= p.cin) { ch -= p.cin; ++tap; }                                                         \
+    if (ch >= p.cslice) { ch -= p.cslice; ++tap; }                                                   \
+    if (tap >= taps) { tap -= taps; ch_base += p.cslice; }                                           \
   }
 
 #define UT_STAGE(buf)                                                                                \
@@ -109,17 +115,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvLaunch p) {
       *reinterpret_cast<u32x4*>(bs_ + (r0 + 32 * i) * LDS_ROW + 4 * g) = b_reg[i];                   \
   }
 
+  const int fr = lane & 31;          // fragment row (A/B) == accumulator column
+  const int fh = lane >> 5;          // k half (A/B) == accumulator row offset 4*fh
+  const int hw = p.Ho * p.Wo;
+
+  // accumulators start at bias (+ residual): the residual tile is fetched here, under the first
+  // im2col fetch, instead of in a serialised load->add->store epilogue
   f32x16 acc[MI][NI];
+  {
+    // the residual goes through a buffer descriptor as well: with no residual the descriptor is
+    // empty and every load returns 0 - one straight-line burst of loads, no per-element branches
+    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.res ? p.res : p.bias), 0,
+        p.res ? (int)((size_t)M * p.cout_store * sizeof(float)) : 0, 0x00020000);
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + wn * (NI * 32) + j * 32 + fr;
+      const float bias = p.bias[n];   // bias is padded to cout_pad
+      const bool n_ok = n < p.cout_store;
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wm * (MI * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          const unsigned off = (n_ok && m < M) ? (unsigned)(m * p.cout_store + n) * 4u : OOB;
+          acc[i][j][e] = bias + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, off, 0, 0));
+        }
+    }
+  }
 
   const int n_chunks = p.k_pad / BK;
-  const int fr = lane & 31;          // fragment row
-  const int fh = lane >> 5;          // k half
 
   UT_FETCH();
   UT_STAGE(0);
@@ -127,7 +152,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvLaunch p) {
 
   for (int c = 0; c < n_chunks; ++c) {
     const int buf = c & 1;
-    if (c + 1 < n_chunks) UT_FETCH();
+    const bool more = c + 1 < n_chunks;
+    if (more) UT_FETCH();
     const float* as = smem + buf * STAGE + (wm * (MI * 32) + fr) * LDS_ROW + 4 * fh;
     const float* bs = smem + buf * STAGE + BM * LDS_ROW + (wn * (NI * 32) + fr) * LDS_ROW + 4 * fh;
 #pragma unroll
@@ -137,6 +163,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvLaunch p) {
       for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDS_ROW + 8 * q);
 #pragma unroll
       for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_ROW + 8 * q);
+      // the next chunk goes to the other LDS buffer while this chunk's last MFMAs are still queued:
+      // the wave reaches the barrier with the matrix pipe busy instead of draining it first
+      if (q == BK / 8 - 1 && more) UT_STAGE(buf ^ 1);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -147,26 +176,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvLaunch p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
         }
     }
-    if (c + 1 < n_chunks) UT_STAGE(buf ^ 1);
     __syncthreads();
   }
 #undef UT_FETCH
 #undef UT_STAGE
 
-  // ---- epilogue
-  const int hw = p.Ho * p.Wo;
+  // ---- epilogue: (ReLU) and store; residual layout == output layout, NHWC only
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int n = n0 + wn * (NI * 32) + j * 32 + fr;
     const bool n_ok = n < p.cout_store;
-    const float bias = p.bias[n];   // bias is padded to cout_pad
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = m0 + wm * (MI * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
         if (n_ok && m < M) {
-          float v = acc[i][j][e] + bias;
+          float v = acc[i][j][e];
           size_t o;
           if (p.out_nchw) {
             int img = m / hw;
@@ -174,7 +200,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvLaunch p) {
           } else {
             o = (size_t)m * p.cout_store + n;
           }
-          if (p.res) v += p.res[o];
           if (p.relu) v = fmaxf(v, 0.f);
           p.out[o] = v;
         }
@@ -200,9 +225,11 @@ static hipError_t launch_cfg(const ConvLaunch& c, hipStream_t s) {
 }
 
 hipError_t launch_conv_igemm(const ConvLaunch& c, hipStream_t s) {
+  if (c.res && c.out_nchw) return hipErrorInvalidValue;
   if (c.cin % 4 != 0 || c.cin < BK || c.k_pad % BK != 0 || c.cout_pad % 128 != 0 || c.ksize * c.ksize > 9)
     return hipErrorInvalidValue;
-  // 32-bit byte offsets into the activation tensor
+  // 32-bit byte offsets into the activation / residual tensors
+  if ((size_t)c.n_img * c.Ho * c.Wo * c.cout_store * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
   if ((size_t)c.n_img * c.H * c.W * c.cin * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
   if (c.cout_store <= 32) return launch_cfg<128, 32, 4, 1>(c, s);
   if (c.cout_store <= 64) return launch_cfg<128, 64, 2, 2>(c, s);

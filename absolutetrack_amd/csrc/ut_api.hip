@@ -20,7 +20,7 @@ struct ConvW {
   float* w = nullptr;     // device [cout_pad][k_pad]
   float* bias = nullptr;  // device [cout_pad]
   int cin = 0, cin_pad = 0, cout = 0, cout_pad = 0, cout_store = 0;
-  int taps = 1, ksize = 1, stride = 1, pad = 0, k_total = 0, k_pad = 0;
+  int taps = 1, ksize = 1, stride = 1, pad = 0, k_total = 0, k_pad = 0, cslice = 0;
   double flops_per_pixel = 0;   // 2 * taps * cin * cout, un-padded
 };
 
@@ -117,7 +117,7 @@ int upload(ut_handle h, const std::vector<float>& host, float** dev) {
 }
 
 // Fold eval-mode BatchNorm (eps 1e-5) into the convolution and pack to [cout_pad][k_pad] with
-// k = tap*cin_pad + c.   y = s*(conv(x)+b-mean)+beta,  s = gamma/sqrt(var+eps)
+// k = slice*(taps*cslice) + tap*cslice + c (see ut_kernels.h).   y = s*(conv(x)+b-mean)+beta,  s = gamma/sqrt(var+eps)
 int pack_conv(ut_handle h, ConvW& cw, const float* w, const float* conv_bias, const BN* bn, int cin, int cout,
               int ksize, int stride, int cout_store) {
   cw.cin = cin; cw.cout = cout; cw.ksize = ksize; cw.stride = stride;
@@ -127,6 +127,7 @@ int pack_conv(ut_handle h, ConvW& cw, const float* w, const float* conv_bias, co
   cw.cout_store = cout_store;
   cw.cout_pad = round_up(cout_store, 128);
   cw.k_total = cw.taps * cw.cin_pad;
+  cw.cslice = cw.cin_pad % 32 == 0 ? 32 : cw.cin_pad;
   cw.k_pad = round_up(cw.k_total, 32);
   cw.flops_per_pixel = 2.0 * cw.taps * cin * cout;
   std::vector<float> wp((size_t)cw.cout_pad * cw.k_pad, 0.f), bp(cw.cout_pad, 0.f);
@@ -139,7 +140,8 @@ int pack_conv(ut_handle h, ConvW& cw, const float* w, const float* conv_bias, co
     bp[o] = (float)shift;
     for (int c = 0; c < cin; ++c)
       for (int t = 0; t < cw.taps; ++t)
-        wp[(size_t)o * cw.k_pad + t * cw.cin_pad + c] = (float)((double)w[((size_t)o * cin + c) * cw.taps + t] * s);
+        wp[(size_t)o * cw.k_pad + (c / cw.cslice) * (cw.taps * cw.cslice) + t * cw.cslice + c % cw.cslice] =
+            (float)((double)w[((size_t)o * cin + c) * cw.taps + t] * s);
   }
   int rc = upload(h, wp, &cw.w);
   if (rc) return rc;
@@ -277,7 +279,7 @@ int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, fl
   c.Ho = (H + 2 * cw.pad - cw.ksize) / cw.stride + 1;
   c.Wo = (W + 2 * cw.pad - cw.ksize) / cw.stride + 1;
   c.cout_store = cw.cout_store; c.cout_pad = cw.cout_pad;
-  c.k_total = cw.k_total; c.k_pad = cw.k_pad;
+  c.k_total = cw.k_total; c.k_pad = cw.k_pad; c.cslice = cw.cslice;
   c.ksize = cw.ksize; c.stride = cw.stride; c.pad = cw.pad;
   c.relu = relu; c.out_nchw = nchw;
   ProfEvent pe{};

@@ -7,7 +7,11 @@ namespace ut {
 
 // One convolution (1x1 or 3x3, stride 1 or 2) as an implicit GEMM over NHWC activations:
 //   out[m][n] = act( sum_k A[m][k] * Wp[n][k] + bias[n] (+ res[m][n]) ),  m = (img, oy, ox)
-// k is ordered (tap, cin); Wp is [cout_pad][k_pad] k-contiguous, zero padded, BatchNorm folded.
+// k is ordered (channel slice, tap, channel in slice) with slices of `cslice` channels:
+//   k = s*(taps*cslice) + tap*cslice + c ,  input channel = s*cslice + c
+// cslice = 32 when cin % 32 == 0 (one K chunk = one tap of one 128-byte channel slice, so the 9 taps
+// of a slice re-read the same cache lines back to back and hit L1), else cslice = cin (tap major).
+// Wp is [cout_pad][k_pad] k-contiguous, zero padded, BatchNorm folded.
 struct ConvLaunch {
   const float* in;     // [n_img, H, W, cin]          (cin % 4 == 0)
   const float* w;      // [cout_pad][k_pad]
@@ -18,6 +22,7 @@ struct ConvLaunch {
   int cout_store;      // channels written per pixel (== channel stride of out / res)
   int cout_pad;        // rows of Wp (multiple of 128)
   int k_total;         // taps * cin
+  int cslice;          // channel slice width of the k order (32 or cin)
   int k_pad;           // row stride of Wp (multiple of 32)
   int ksize, stride, pad;
   int relu;

@@ -1,31 +1,61 @@
 #!/usr/bin/env python3
-"""Summarise a rocprofv3 --kernel-trace CSV of bench.py: per-kernel totals and, for the conv_igemm
-kernel, per-(grid, instantiation) average durations of the last step.  Usage:
-    python tools_layer_profile.py <kernel_trace.csv> [launches_per_step]"""
+"""Per-layer view of a rocprofv3 --kernel-trace CSV of `bench.py` (known-skeleton mode):
+maps the conv_igemm launches of the LAST step to the network's convolutions by launch order and
+prints duration, FLOPs and TFLOP/s of each, plus totals of every other kernel in that step.
+    python tools/layer_profile.py <kernel_trace.csv> <n_crops> <chunk>"""
 import collections
 import csv
 import sys
 
-rows = list(csv.DictReader(open(sys.argv[1])))
+path, n_crops, chunk = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-tot = collections.defaultdict(lambda: [0, 0.0])
-for r in rows:
-    k = r["Kernel_Name"].split("(")[0][-60:]
-    tot[k][0] += 1
-    tot[k][1] += dur(r)
-print("kernel totals (whole run):")
-for k, (n, t) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:14]:
-    print(f"  {t/1e3:10.3f} ms  {n:6d} calls  {t/n:9.1f} us avg  {k}")
+
+blocks = [(32, 32, 1), (32, 32, 1), (32, 64, 2), (64, 64, 1), (64, 64, 1), (64, 128, 2), (128, 128, 1), (128, 128, 1),
+          (128, 128, 1), (128, 128, 1), (128, 256, 2), (256, 256, 1)]
+def block_convs(bi, hw):
+    ci, co, s = blocks[bi]
+    ho = hw // s
+    out = [(f"b{bi}.conv1 {ci}->{co} s{s} @{ho}", 2 * 9 * ci * co * ho * ho)]
+    if s != 1 or ci != co:
+        out.append((f"b{bi}.ds {ci}->{co} @{ho}", 2 * ci * co * ho * ho))
+    out.append((f"b{bi}.conv2 {co}->{co} @{ho}", 2 * 9 * co * co * ho * ho))
+    return out, ho
+
+seq = []   # (name, flops for the launch)
+n_chunks = (n_crops + chunk - 1) // chunk
+for c in range(n_chunks):
+    n = min(chunk, n_crops - c * chunk)
+    hw = 48
+    for bi in range(5):
+        cs, hw = block_convs(bi, hw)
+        seq += [(nm, fl * n) for nm, fl in cs]
+hw = 24
+for bi in range(5, 12):
+    cs, hw = block_convs(bi, hw)
+    seq += [(nm, fl * n_crops) for nm, fl in cs]
+seq.append(("proj 256->72", 2 * 256 * 72 * 36 * n_crops))
+s = n_crops // 2
+head = [("fus0 144->108", 144 * 108), ("fus1 108->72", 108 * 72), ("fus2 72->72", 72 * 72), ("tmp0 90->90", 8100),
+        ("tmp1 90->90", 8100), ("tmp2 90->90", 8100), ("reg0.conv1 76", 9 * 76 * 76), ("reg0.conv2 76", 9 * 76 * 76),
+        ("reg1.conv1 76", 9 * 76 * 76), ("reg1.conv2 76", 9 * 76 * 76)]
+seq += [(nm, 2 * mac * 36 * s) for nm, mac in head]
+
 convs = [r for r in rows if "conv_igemm" in r["Kernel_Name"]]
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-if n:
-    last = convs[-n:]
-    groups = collections.OrderedDict()
-    for r in last:
-        key = (r["Kernel_Name"].split("<")[1].split(">")[0], r["Grid_Size_X"], r["Grid_Size_Y"])
-        groups.setdefault(key, []).append(dur(r))
-    print("last step, conv_igemm by (tile, grid):")
-    for k, v in groups.items():
-        print(f"  {k}: {len(v):3d} launches, avg {sum(v)/len(v):8.1f} us, total {sum(v)/1e3:7.3f} ms")
-    print(f"  step conv total {sum(dur(r) for r in last)/1e3:.3f} ms")
+last = convs[-len(seq):]
+agg = collections.OrderedDict()
+for (nm, fl), r in zip(seq, last):
+    a = agg.setdefault(nm, [0, 0.0, 0.0, r["Kernel_Name"].split("<")[1].split(">")[0]])
+    a[0] += 1; a[1] += dur(r); a[2] += fl
+tot_t = sum(a[1] for a in agg.values()); tot_f = sum(a[2] for a in agg.values())
+print(f"{'conv':28s} {'tile':16s} {'n':>3s} {'total us':>10s} {'TFLOP/s':>8s} {'% of conv time':>8s}")
+for nm, (n, t, fl, tile) in agg.items():
+    print(f"{nm:28s} {tile:16s} {n:3d} {t:10.1f} {fl/t/1e6:8.1f} {100*t/tot_t:8.2f}")
+print(f"conv total {tot_t/1e3:.3f} ms, {tot_f/tot_t/1e6:.1f} TFLOP/s")
+t0 = int(last[0]["Start_Timestamp"])
+others = collections.Counter()
+for r in rows:
+    if int(r["Start_Timestamp"]) >= t0 - 2e6 and "conv_igemm" not in r["Kernel_Name"]:
+        others[r["Kernel_Name"].split("(")[0][-48:]] += dur(r)
+print("other kernels in/around the last step (us):", {k: round(v, 1) for k, v in others.most_common(10)})
