@@ -22,7 +22,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", "-o", OUT] + [os.path.join(CSRC, f) for f in SOURCES]
+           "-Wno-unused-function", "-o", OUT] + os.environ.get("UT_EXTRA_HIPCC_FLAGS", "").split() \
+        + [os.path.join(CSRC, f) for f in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

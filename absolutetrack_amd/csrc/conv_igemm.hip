@@ -5,17 +5,27 @@
 // :141-163 (fusion), lib/models/temporal.py:31-38, lib/models/model_utils.py:195-208 (regressor).
 //
 // GEMM view: M = n_img*Ho*Wo output pixels, N = cout, K = taps*cin, k ordered (channel slice, tap,
-// channel) - see ut_kernels.h.
-// Activations are NHWC so a k-run of 4 channels is one 16-byte load; weights are pre-packed
-// [cout_pad][k_pad] (k contiguous) with BatchNorm folded in.  A workgroup (4 waves, 256 threads)
-// owns a BM x BN output tile and walks K in chunks of 32:
-//   global (im2col gather, zero fill at the borders) -> registers -> LDS (double buffered,
-//   rows padded to 36 floats so ds_read_b128 fragment reads are bank-conflict free)
-//   -> one ds_read_b128 per 32-row fragment per 8 k  -> 4 MFMA 32x32x2 per fragment pair.
-// Lane l of a wave holds row (l&31) of the fragment and k-half (l>>5); the 4 floats of a b128
-// read feed 4 consecutive MFMAs (k order inside the 8-run is permuted identically for A and B).
-// Epilogue: bias (+residual) (+ReLU) from the accumulator layout col = lane&31,
-// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// channel) - see ut_kernels.h.  Activations are NHWC so a k-run of 4 channels is one 16-byte load;
+// weights are pre-packed [cout_pad][k_pad] (k contiguous) with BatchNorm folded in.
+//
+// A workgroup (4 waves, 256 threads) computes BM x BN output tiles and walks K in chunks of 32:
+//   buffer loads (im2col gather; out-of-image taps get an out-of-range offset and read as 0, so the load
+//   path has no branches) -> registers -> LDS (double buffered, rows padded to 36 floats so that the
+//   ds_read_b128 fragment reads are bank-conflict free) -> 4 MFMA 32x32x2 per fragment pair.
+// Lane l of a wave holds row (l&31) of the fragment and k-half (l>>5); the 4 floats of a b128 read feed
+// 4 consecutive MFMAs (the k order inside the 8-run is permuted identically for A and B).
+//
+// Workgroups are PERSISTENT: a grid of (CUs x resident blocks) walks the tile list, and the first chunk,
+// bias and residual of the next tile are fetched under the last chunk of the current one.  A 64-cycle MFMA
+// makes operand traffic cheap; what costs throughput is every cycle the matrix pipe waits for a tile
+// prologue (index math, first-touch HBM latency, residual fetch), and co-resident workgroups with equal
+// work fall into lockstep so that their prologues coincide.  With the prologue hidden the per-tile bubble
+// is the accumulator drain + store issue only.
+// Accumulators start at bias (+ residual); epilogue = (ReLU) + store.  The weights are the MFMA "A" operand
+// and the pixels the "B" operand, so in the C layout (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
+// a lane owns one pixel and register quads are 4 consecutive channels: 16-byte NHWC loads and stores.
+#include <stdlib.h>
+
 #include "ut_kernels.h"
 
 namespace ut {
@@ -26,14 +36,24 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int BK = 32;
 constexpr int LDS_ROW = BK + 4;   // floats; 144 B row stride = 9 x 16 B -> conflict-free b128 reads
 
+// n / d for 0 <= n < 2^24 via a float reciprocal and one correction step (exact: |error| <= 1 before it)
+__device__ __forceinline__ int fast_div(int n, int d, float inv_d) {
+  int q = (int)((float)n * inv_d);
+  int r = n - q * d;
+  if (r < 0) --q;
+  if (r >= d) ++q;
+  return q;
+}
+
 template <int BM, int BN, int WR, int WC>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvLaunch p) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int tiles_n, int n_tiles) {
   static_assert(WR * WC == 4, "4 waves per workgroup");
   constexpr int MI = BM / WR / 32;   // 32x32 accumulator tiles per wave along M
   constexpr int NI = BN / WC / 32;   // ... along N
   constexpr int AP = BM / 32;        // 16-byte loads per thread per chunk for the A tile
   constexpr int BP = BN / 32;
   constexpr int STAGE = (BM + BN) * LDS_ROW;
+  constexpr unsigned OOB = 0xFFFFFF00u;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -43,66 +63,119 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvLaunch p) {
   const int wm = wave / WC, wn = wave % WC;
   const int g = tid & 7;        // which 4-float group of the 32-wide k chunk this thread stages
   const int r0 = tid >> 3;      // first tile row this thread stages (then +32 per pass)
+  const int fr = lane & 31;     // fragment row (A/B) == accumulator column
+  const int fh = lane >> 5;     // k half (A/B) == accumulator row offset 4*fh
 
   const int M = p.n_img * p.Ho * p.Wo;
-  const int m0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  const int hw = p.Ho * p.Wo;
+  const float inv_hw = 1.0f / (float)hw, inv_wo = 1.0f / (float)p.Wo;
+  const int taps = p.ksize * p.ksize;
+  const int n_chunks = p.k_pad / BK;
+  const unsigned b_row_step = (unsigned)(32 * p.k_pad * 4);
 
-  // ---- per-thread im2col row bookkeeping (fixed over the K loop)
-  // Activations and weights are read through raw buffer descriptors: a tap that falls outside the
-  // image (or a row beyond M) gets an out-of-range offset and the hardware returns zeros - no
-  // branches and no selects on the load path, so the loads stay in flight under the MFMAs.
-  // k beyond taps*cin needs no masking: the packed weights are zero there and every address that
-  // passes the bounds test holds a finite activation.
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.in), 0, (int)((size_t)p.n_img * p.H * p.W * p.cin * sizeof(float)), 0x00020000);
   const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.w), 0, (int)((size_t)p.cout_pad * p.k_pad * sizeof(float)), 0x00020000);
-  constexpr unsigned OOB = 0xFFFFFF00u;
-  int a_pix[AP];                 // element offset of the (iy0, ix0) pixel of this row (may be "negative")
-  int a_iy[AP], a_ix[AP];
-#pragma unroll
-  for (int i = 0; i < AP; ++i) {
-    int m = m0 + r0 + 32 * i;
-    bool ok = m < M;
-    int mm = ok ? m : 0;
-    int img = mm / (p.Ho * p.Wo);
-    int rem = mm - img * (p.Ho * p.Wo);
-    int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-    a_iy[i] = ok ? oy * p.stride - p.pad : -100000;   // rows beyond M never pass the bounds test
-    a_ix[i] = ox * p.stride - p.pad;
-    a_pix[i] = ((img * p.H + a_iy[i]) * p.W + a_ix[i]) * p.cin;
-  }
-  unsigned b_off = (unsigned)(((n0 + r0) * p.k_pad + 4 * g) * 4);
-  const unsigned b_row_step = (unsigned)(32 * p.k_pad * 4);
+  // with no residual the descriptor is empty and every load returns 0
+  const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.res ? p.res : p.bias), 0, p.res ? (int)((size_t)M * p.cout_store * sizeof(float)) : 0,
+      0x00020000);
 
-  // (slice, tap, channel in slice) of this thread's 4-float group; cslice >= 32, so one step of 32
-  // crosses at most one tap boundary, and taps wrap into the next channel slice
-  const int taps = p.ksize * p.ksize;
-  int tap = (4 * g) / p.cslice;
-  int ch = 4 * g - tap * p.cslice;
-  int ch_base = 0;                // first channel of the current slice
-  if (tap >= taps) { tap -= taps; ch_base = p.cslice; }
+  const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      p.out, 0, (int)((size_t)M * p.cout_store * sizeof(float)), 0x00020000);
 
+  // XCD-aware tile order: workgroups b, b+8, ... share an XCD (and its L2); give each XCD a contiguous
+  // run of tiles per round so that neighbouring tiles (shared halo rows, same weights) meet in one L2.
+  const int grid = gridDim.x;
+  int slot = blockIdx.x;
+  if ((grid & 7) == 0) slot = (blockIdx.x & 7) * (grid >> 3) + (blockIdx.x >> 3);
+
+  // ---- fetch-side state: im2col rows of the tile being FETCHED and its position in K
+  int a_pix[AP], a_iy[AP], a_ix[AP];
+  unsigned b_off;
+  int tap, ch, ch_base;
   u32x4 a_reg[AP], b_reg[BP];
+  f32x16 init[MI][NI];          // bias (+ residual) of the tile being fetched
 
-#define UT_FETCH()                                                                                   \
+#ifdef UT_DIAG_NO_A   /* timing-only ablations (tools/diag) */
+#define UT_DIAG_A(x) asm volatile("" ::"v"(off))
+#else
+#define UT_DIAG_A(x) x
+#endif
+#ifdef UT_DIAG_NO_B
+#define UT_DIAG_B(x)
+#else
+#define UT_DIAG_B(x) x
+#endif
+#define UT_SETUP(TILE)                                                                               \
+  {                                                                                                  \
+    const int tm_ = (TILE) / tiles_n, tn_ = (TILE) - tm_ * tiles_n;                                  \
+    _Pragma("unroll") for (int i = 0; i < AP; ++i) {                                                 \
+      const int m = tm_ * BM + r0 + 32 * i;                                                          \
+      const bool ok = m < M;                                                                         \
+      const int mm = ok ? m : 0;                                                                     \
+      const int img = fast_div(mm, hw, inv_hw);                                                      \
+      const int rem = mm - img * hw;                                                                 \
+      const int oy = fast_div(rem, p.Wo, inv_wo), ox = rem - oy * p.Wo;                              \
+      a_iy[i] = ok ? oy * p.stride - p.pad : -100000; /* rows beyond M never pass the bounds test */ \
+      a_ix[i] = ox * p.stride - p.pad;                                                               \
+      a_pix[i] = ((img * p.H + a_iy[i]) * p.W + a_ix[i]) * p.cin;                                    \
+    }                                                                                                \
+    b_off = (unsigned)(((tn_ * BN + r0) * p.k_pad + 4 * g) * 4);                                     \
+    /* (slice, tap, channel in slice) of this thread's 4-float group: cslice >= 32 */                \
+    tap = 0; ch = 4 * g; ch_base = 0;                                                                \
+  }
+
+  // The AP+BP 16-byte loads of a chunk are issued in three parts, one in front of each of the first three
+  // MFMA groups, instead of in one burst behind the barrier: all waves of a workgroup leave the barrier
+  // together, and a burst of 8 loads x 4 waves backs up the address path so that the last wave cannot start
+  // its MFMAs (instructions issue in order) until its loads have been accepted.
+#define UT_FETCH_PART(PART)                                                                          \
   {                                                                                                  \
     int dy = 0, dx = 0;                                                                              \
     if (p.ksize == 3) { dy = (tap * 11) >> 5; dx = tap - 3 * dy; } /* tap/3 for tap < 32 */         \
     const int tap_off = (dy * p.W + dx) * p.cin + ch_base + ch;                                      \
-    _Pragma("unroll") for (int i = 0; i < AP; ++i) {                                                 \
+    _Pragma("unroll") for (int i = 0; i < AP; ++i) if (i % 3 == (PART)) {                            \
       const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;                                                \
       const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;                  \
       const unsigned off = ok ? (unsigned)(a_pix[i] + tap_off) * 4u : OOB;                           \
-      a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off, 0, 0);                           \
+      UT_DIAG_A(a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off, 0, 0));                \
     }                                                                                                \
-    _Pragma("unroll") for (int i = 0; i < BP; ++i)                                                   \
-      b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off + i * b_row_step, 0, 0);        \
-    b_off += BK * 4;                                                                                 \
-    ch += BK;                                                                                        \
-    if (ch >= p.cslice) { ch -= p.cslice; ++tap; }                                                   \
-    if (tap >= taps) { tap -= taps; ch_base += p.cslice; }                                           \
+    _Pragma("unroll") for (int i = 0; i < BP; ++i) if ((i + AP) % 3 == (PART))                       \
+      UT_DIAG_B(b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off + i * b_row_step, 0, 0)); \
+    if ((PART) == 2) { /* advance to the next chunk */                                               \
+      b_off += BK * 4;                                                                               \
+      ch += BK;                                                                                      \
+      if (ch >= p.cslice) { ch -= p.cslice; ++tap; }                                                 \
+      if (tap >= taps) { tap -= taps; ch_base += p.cslice; }                                         \
+    }                                                                                                \
+  }
+#define UT_FETCH() { UT_FETCH_PART(0); UT_FETCH_PART(1); UT_FETCH_PART(2); }
+
+  // MFMA C layout with the operands as above: lane = pixel (column fr of the 32-pixel fragment), register e =
+  // output channel (e&3) + 8*(e>>2) + 4*fh of the 32-channel fragment.  Four consecutive registers are four
+  // consecutive channels of one pixel: one 16-byte access in NHWC.
+#define UT_INIT_LOAD(TILE)                                                                           \
+  {                                                                                                  \
+    const int tm_ = (TILE) / tiles_n, tn_ = (TILE) - tm_ * tiles_n;                                  \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                 \
+      const int m = tm_ * BM + wm * (MI * 32) + i * 32 + fr;                                         \
+      const bool m_ok = m < M;                                                                       \
+      _Pragma("unroll") for (int j = 0; j < NI; ++j) {                                               \
+        _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4) {                                           \
+          const int n = tn_ * BN + wn * (NI * 32) + j * 32 + 8 * g4 + 4 * fh;                        \
+          const float4 bias = *reinterpret_cast<const float4*>(p.bias + n); /* padded to cout_pad */ \
+          const unsigned off = (m_ok && n < p.cout_store) ? (unsigned)(m * p.cout_store + n) * 4u : OOB; \
+          /* NB: __builtin_bit_cast on a vector ELEMENT (r.y) miscompiles to a splat of r.x (ROCm 7.2) */  \
+          const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0);                  \
+          init[i][j][4 * g4 + 0] = bias.x + __uint_as_float(r.x);                          \
+          init[i][j][4 * g4 + 1] = bias.y + __uint_as_float(r.y);                          \
+          init[i][j][4 * g4 + 2] = bias.z + __uint_as_float(r.z);                          \
+          init[i][j][4 * g4 + 3] = bias.w + __uint_as_float(r.w);                          \
+        }                                                                                            \
+      }                                                                                              \
+    }                                                                                                \
   }
 
 #define UT_STAGE(buf)                                                                                \
@@ -115,104 +188,197 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvLaunch p) {
       *reinterpret_cast<u32x4*>(bs_ + (r0 + 32 * i) * LDS_ROW + 4 * g) = b_reg[i];                   \
   }
 
-  const int fr = lane & 31;          // fragment row (A/B) == accumulator column
-  const int fh = lane >> 5;          // k half (A/B) == accumulator row offset 4*fh
-  const int hw = p.Ho * p.Wo;
+#ifdef UT_DIAG_NO_STAGE
+#define UT_MAYBE_STAGE(b) asm volatile("" ::"v"(a_reg[0]), "v"(b_reg[0]))
+#else
+#define UT_MAYBE_STAGE(b) UT_STAGE(b)
+#endif
 
-  // accumulators start at bias (+ residual): the residual tile is fetched here, under the first
-  // im2col fetch, instead of in a serialised load->add->store epilogue
-  f32x16 acc[MI][NI];
-  {
-    // the residual goes through a buffer descriptor as well: with no residual the descriptor is
-    // empty and every load returns 0 - one straight-line burst of loads, no per-element branches
-    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.res ? p.res : p.bias), 0,
-        p.res ? (int)((size_t)M * p.cout_store * sizeof(float)) : 0, 0x00020000);
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int n = n0 + wn * (NI * 32) + j * 32 + fr;
-      const float bias = p.bias[n];   // bias is padded to cout_pad
-      const bool n_ok = n < p.cout_store;
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = m0 + wm * (MI * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-          const unsigned off = (n_ok && m < M) ? (unsigned)(m * p.cout_store + n) * 4u : OOB;
-          acc[i][j][e] = bias + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, off, 0, 0));
-        }
-    }
+  // Fragment reads (one b128 per 32-row fragment per 8 k) into register set X or Y, and the 4*MI*NI MFMAs
+  // that consume a set.
+#define UT_READ(SET, buf, q)                                                                         \
+  {                                                                                                  \
+    const float* as = smem + (buf) * STAGE + (wm * (MI * 32) + fr) * LDS_ROW + 4 * fh + 8 * (q);     \
+    const float* bs = smem + (buf) * STAGE + BM * LDS_ROW + (wn * (NI * 32) + fr) * LDS_ROW + 4 * fh + 8 * (q); \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) af##SET[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDS_ROW); \
+    _Pragma("unroll") for (int j = 0; j < NI; ++j) bf##SET[j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_ROW); \
   }
+#define UT_MFMA(SET)                                                                                 \
+  {                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
+      _Pragma("unroll") for (int j = 0; j < NI; ++j) {                                               \
+        /* weights are the MFMA "A" operand, pixels the "B" operand: D = W x im2col^T, so a lane owns ONE     \
+           pixel (column) and 4 consecutive output channels per register quad - 16-byte NHWC accesses */      \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[j].x, af##SET[i].x, acc[i][j], 0, 0, 0); \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[j].y, af##SET[i].y, acc[i][j], 0, 0, 0); \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[j].z, af##SET[i].z, acc[i][j], 0, 0, 0); \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[j].w, af##SET[i].w, acc[i][j], 0, 0, 0); \
+      }                                                                                              \
+  }
+#define UT_PIN() __builtin_amdgcn_sched_barrier(0)
 
-  const int n_chunks = p.k_pad / BK;
+  // One chunk, software pipelined against LDS latency and the barrier.  On entry set X holds the q=0
+  // fragments of this chunk (read under the previous chunk's last MFMA group).  The reads of group q+1 are
+  // issued before the MFMAs of group q; the next chunk is staged and the barrier passed BEFORE the last
+  // MFMA group, under which the q=0 fragments of the next chunk are read from the other buffer.
+#define UT_CHUNK(buf, F0, F1, F2)                                                                    \
+  {                                                                                                  \
+    F0; UT_READ(Y, buf, 1); UT_PIN(); UT_MFMA(X); UT_PIN();                                          \
+    F1; UT_READ(X, buf, 2); UT_PIN(); UT_MFMA(Y); UT_PIN();                                          \
+    F2; UT_READ(Y, buf, 3); UT_PIN(); UT_MFMA(X); UT_PIN();                                          \
+    UT_MAYBE_STAGE((buf) ^ 1);                                                                       \
+    UT_BARRIER();                                                                                    \
+    UT_READ(X, (buf) ^ 1, 0); UT_PIN(); UT_MFMA(Y); UT_PIN();                                        \
+  }
+#ifdef UT_DIAG_NO_BARRIER
+#define UT_BARRIER()
+#else
+#define UT_BARRIER() __syncthreads()
+#endif
 
+#ifdef UT_STAMPS
+#define UT_STAMP(IDX)                                                                                \
+  if (tid == 0 && blockIdx.x < 4096) {                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+    p.stamps[blockIdx.x * 8 + (IDX)] = (long long)__builtin_amdgcn_s_memtime();                      \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+  }
+  int tiles_done = 0;
+#else
+#define UT_STAMP(IDX)
+#endif
+  UT_STAMP(0);
+  // Stagger the workgroups that share a CU.  Co-resident workgroups run the same program on the same
+  // pipes; sharing the matrix pipe preserves their phase difference, and they are dispatched together, so
+  // without this they stay in lockstep for the whole (persistent) kernel: every non-MFMA stretch of a chunk
+  // (address math, load issue, barrier) then idles the pipe.  A one-time delay of 1/k of a chunk's MFMA time
+  // per co-resident rank keeps one workgroup in its MFMA stretch while the other is between chunks.
+  {
+    const int rank = __builtin_amdgcn_readfirstlane((int)blockIdx.x / p.num_cu);   // 0 .. resident-1
+    const int steps = rank * p.stagger;       // units of 512 cycles
+    for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(8);
+  }
+  int tile = slot;
+  UT_SETUP(tile);
   UT_FETCH();
+  UT_INIT_LOAD(tile);
   UT_STAGE(0);
   __syncthreads();
+  UT_STAMP(1);
 
-  for (int c = 0; c < n_chunks; ++c) {
-    const int buf = c & 1;
-    const bool more = c + 1 < n_chunks;
-    if (more) UT_FETCH();
-    const float* as = smem + buf * STAGE + (wm * (MI * 32) + fr) * LDS_ROW + 4 * fh;
-    const float* bs = smem + buf * STAGE + BM * LDS_ROW + (wn * (NI * 32) + fr) * LDS_ROW + 4 * fh;
+  int buf = 0;
+  f32x16 acc[MI][NI];
+  float4 afX[MI], bfX[NI], afY[MI], bfY[NI];
+  UT_READ(X, 0, 0);
+  for (;;) {
 #pragma unroll
-    for (int q = 0; q < BK / 8; ++q) {
-      float4 af[MI], bf[NI];
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDS_ROW + 8 * q);
-#pragma unroll
-      for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_ROW + 8 * q);
-      // the next chunk goes to the other LDS buffer while this chunk's last MFMAs are still queued:
-      // the wave reaches the barrier with the matrix pipe busy instead of draining it first
-      if (q == BK / 8 - 1 && more) UT_STAGE(buf ^ 1);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-        }
+      for (int j = 0; j < NI; ++j) acc[i][j] = init[i][j];
+
+    // steady state: fetch chunk c+1 (loads stay in flight under the MFMAs), compute chunk c
+    for (int c = 0; c + 1 < n_chunks; ++c) {
+#ifndef UT_DIAG_NO_FETCH    /* timing-only ablations for tools/diag (results are wrong with any of them) */
+#ifdef UT_BURST_FETCH
+      UT_FETCH();
+      UT_CHUNK(buf, , , );
+#else
+      UT_CHUNK(buf, UT_FETCH_PART(0), UT_FETCH_PART(1), UT_FETCH_PART(2));
+#endif
+#else
+      UT_CHUNK(buf, , , );
+#endif
+      buf ^= 1;
     }
-    __syncthreads();
-  }
-#undef UT_FETCH
-#undef UT_STAGE
+#ifdef UT_STAMPS
+    if (tiles_done == 0) UT_STAMP(2);
+#endif
+    // last chunk: fetch the first chunk, bias and residual of the NEXT tile under it (without a next tile the
+    // staging inside UT_CHUNK rewrites stale registers into the idle buffer: harmless)
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int next = tile + grid;
+    const bool has_next = next < n_tiles;
+    if (has_next) {
+      UT_SETUP(next);
+      UT_FETCH();
+      UT_INIT_LOAD(next);
+    }
+    UT_CHUNK(buf, , , );
+    buf ^= 1;
+#ifdef UT_STAMPS
+    if (tiles_done == 0) UT_STAMP(3);
+#endif
 
-  // ---- epilogue: (ReLU) and store; residual layout == output layout, NHWC only
-#pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int n = n0 + wn * (NI * 32) + j * 32 + fr;
-    const bool n_ok = n < p.cout_store;
+    // epilogue of the finished tile: (ReLU) + store through a buffer descriptor (pixels beyond M and channel
+    // quads beyond cout get an out-of-range offset and are dropped): straight-line 16-byte stores, so the
+    // compiler counts them exactly instead of draining the memory pipe before the next tile.
+    const int m0 = tm * BM, n0 = tn * BN;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+      const int m = m0 + wm * (MI * 32) + i * 32 + fr;
+      const bool m_ok = m < M;
+      const int img = p.out_nchw ? fast_div(m_ok ? m : 0, hw, inv_hw) : 0;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * (MI * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        if (n_ok && m < M) {
-          float v = acc[i][j][e];
-          size_t o;
-          if (p.out_nchw) {
-            int img = m / hw;
-            o = ((size_t)img * p.cout_store + n) * hw + (m - img * hw);
-          } else {
-            o = (size_t)m * p.cout_store + n;
+      for (int j = 0; j < NI; ++j) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int n = n0 + wn * (NI * 32) + j * 32 + 8 * g4 + 4 * fh;
+          float v[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            v[k] = acc[i][j][4 * g4 + k];
+            if (p.relu) v[k] = fmaxf(v[k], 0.f);
           }
-          if (p.relu) v = fmaxf(v, 0.f);
-          p.out[o] = v;
+          if (!p.out_nchw) {
+            const unsigned off = (m_ok && n < p.cout_store) ? (unsigned)(m * p.cout_store + n) * 4u : OOB;
+            u32x4 pk;
+            pk.x = __float_as_uint(v[0]); pk.y = __float_as_uint(v[1]);
+            pk.z = __float_as_uint(v[2]); pk.w = __float_as_uint(v[3]);
+            __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, off, 0, 0);
+          } else {
+            // NCHW (projection only): channel stride hw, one dword per channel
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const unsigned off = (m_ok && n + k < p.cout_store)
+                                       ? (unsigned)((img * p.cout_store + n + k) * hw + (m - img * hw)) * 4u : OOB;
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[k]), o_rsrc, off, 0, 0);
+            }
+          }
         }
       }
     }
+#ifdef UT_STAMPS
+    if (tiles_done == 0) UT_STAMP(4);
+    if (tiles_done == 1) UT_STAMP(5);
+    ++tiles_done;
+#endif
+    if (!has_next) break;
+    tile = next;
   }
+#ifdef UT_STAMPS
+  UT_STAMP(6);
+  if (tid == 0 && blockIdx.x < 4096) p.stamps[blockIdx.x * 8 + 7] = tiles_done;
+#endif
+#undef UT_SETUP
+#undef UT_FETCH
+#undef UT_FETCH_PART
+#undef UT_INIT_LOAD
+#undef UT_STAGE
+#undef UT_CHUNK
+#undef UT_READ
+#undef UT_MFMA
+#undef UT_PIN
+#undef UT_BARRIER
+#undef UT_MAYBE_STAGE
 }
 
 template <int BM, int BN, int WR, int WC>
 static hipError_t launch_cfg(const ConvLaunch& c, hipStream_t s) {
   const int M = c.n_img * c.Ho * c.Wo;
-  dim3 grid((M + BM - 1) / BM, (c.cout_store + BN - 1) / BN);
-  size_t lds = 2 * (size_t)(BM + BN) * LDS_ROW * sizeof(float);
+  const int tiles_m = (M + BM - 1) / BM;
+  const int tiles_n = (c.cout_store + BN - 1) / BN;
+  const int n_tiles = tiles_m * tiles_n;
+  const size_t lds = 2 * (size_t)(BM + BN) * LDS_ROW * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC>),
@@ -220,17 +386,28 @@ static hipError_t launch_cfg(const ConvLaunch& c, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC>), grid, dim3(256), lds, s, c);
+  // persistent grid: as many workgroups as stay resident (LDS bound), never more than tiles
+  const int per_cu = (int)((160 * 1024) / lds);
+  int grid = c.num_cu * (per_cu < 1 ? 1 : per_cu);
+  if (c.persist_limit > 0 && grid > c.persist_limit) grid = c.persist_limit;
+  if (c.persist_limit < 0) grid = n_tiles;     // one tile per workgroup (hardware dispatch order)
+  if (grid > n_tiles) grid = n_tiles;
+  // automatic stagger: with r co-resident workgroups a chunk takes r x (its MFMA time) of wall time, so the
+  // even spacing between ranks is one chunk's MFMA time = (MI*NI) x 16 MFMAs x 64 cycles = (MI*NI) x 2 units
+  ConvLaunch cl = c;
+  if (c.stagger < 0) cl.stagger = grid > c.num_cu ? (BM / WR / 32) * (BN / WC / 32) * 2 : 0;
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC>), dim3(grid), dim3(256), lds, s, cl, tiles_n, n_tiles);
   return hipGetLastError();
 }
 
 hipError_t launch_conv_igemm(const ConvLaunch& c, hipStream_t s) {
   if (c.res && c.out_nchw) return hipErrorInvalidValue;
-  if (c.cin % 4 != 0 || c.cin < BK || c.k_pad % BK != 0 || c.cout_pad % 128 != 0 || c.ksize * c.ksize > 9)
+  if (c.cin % 4 != 0 || c.cslice < BK || c.k_pad % BK != 0 || c.cout_pad % 128 != 0 || c.ksize * c.ksize > 9 ||
+      c.num_cu <= 0)
     return hipErrorInvalidValue;
   // 32-bit byte offsets into the activation / residual tensors
-  if ((size_t)c.n_img * c.Ho * c.Wo * c.cout_store * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
   if ((size_t)c.n_img * c.H * c.W * c.cin * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
+  if ((size_t)c.n_img * c.Ho * c.Wo * c.cout_store * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
   if (c.cout_store <= 32) return launch_cfg<128, 32, 4, 1>(c, s);
   if (c.cout_store <= 64) return launch_cfg<128, 64, 2, 2>(c, s);
   return launch_cfg<128, 128, 2, 2>(c, s);

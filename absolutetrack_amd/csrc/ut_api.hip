@@ -5,6 +5,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -42,6 +43,9 @@ struct ProfEvent { hipEvent_t a, b; double flops; };
 
 struct ut_context {
   int device = 0;
+  int num_cu = 256;
+  int persist_limit = 0;
+  int stagger = -1;
   std::string err;
   std::vector<void*> allocs;        // everything to hipFree at destroy
   // weights
@@ -53,7 +57,7 @@ struct ut_context {
   // backbone workspace.  Phase A (stem, layer1, layer2) runs in passes of `chunk` crops so that its
   // large activations stay cache resident; phase B (layer3, layer4, projection) runs over up to
   // PHASE_B_MAX crops at once so that the small late maps still fill the chip with workgroups.
-  int chunk = 512;
+  int chunk = 1024;
   int ws_crops = 0;       // phase-A capacity (crops)
   float *bufX = nullptr, *bufH = nullptr, *bufY = nullptr, *bufD = nullptr;
   int wsb_crops = 0;      // phase-B capacity (crops)
@@ -282,6 +286,7 @@ int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, fl
   c.k_total = cw.k_total; c.k_pad = cw.k_pad; c.cslice = cw.cslice;
   c.ksize = cw.ksize; c.stride = cw.stride; c.pad = cw.pad;
   c.relu = relu; c.out_nchw = nchw;
+  c.num_cu = h->num_cu; c.persist_limit = h->persist_limit; c.stagger = h->stagger;
   ProfEvent pe{};
   if (h->profiling) {
     HIPCHK(h, hipEventCreate(&pe.a));
@@ -326,6 +331,12 @@ int ut_create(int device, const float* blob, size_t n_floats, ut_handle* out) {
   if (e != hipSuccess) return fail(nullptr, UT_E_HIP, "hipSetDevice", e);
   ut_handle h = new ut_context();
   h->device = device;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->num_cu = cus;
+    if (const char* e = getenv("UT_PERSIST_LIMIT")) h->persist_limit = atoi(e);
+    if (const char* e = getenv("UT_STAGGER")) h->stagger = atoi(e);
+  }
   Cursor c{blob, n_floats};
   int rc = UT_OK;
   do {
@@ -405,7 +416,7 @@ int ut_destroy(ut_handle h) {
 
 int ut_set_backbone_chunk(ut_handle h, int crops_per_pass) {
   if (!h || crops_per_pass < 0) return fail(h, UT_E_INVALID, "ut_set_backbone_chunk: bad argument");
-  h->chunk = crops_per_pass == 0 ? 512 : crops_per_pass;
+  h->chunk = crops_per_pass == 0 ? 1024 : crops_per_pass;
   return UT_OK;
 }
 

@@ -27,6 +27,12 @@ struct ConvLaunch {
   int ksize, stride, pad;
   int relu;
   int out_nchw;
+  int num_cu;          // compute units of the device (persistent grid sizing)
+  int persist_limit;   // > 0: cap on the persistent grid (debug / tuning)
+  int stagger;         // start delay per co-resident workgroup rank, units of 512 cycles; < 0 = automatic
+#ifdef UT_STAMPS
+  long long* stamps;   // diagnostic builds only (tools/diag): [workgroup][8] s_memtime stamps
+#endif
 };
 
 hipError_t launch_conv_igemm(const ConvLaunch& c, hipStream_t s);
