@@ -119,9 +119,15 @@ def main():
             hot.step(batch)
         ms, launches, flops = eng.profile_end()
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command (FETCH_SIZE and
+        # WRITE_SIZE cannot share a pass), summarised by tools/pmc_traffic.py into profiles/
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
+        if os.path.exists(tpath) and f_local == 1024 and known:
+            traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
         roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (all instantiations)",
                     "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "launches_per_step": launches // n_prof, "avg_launch_ms": round(ms / max(launches, 1), 5),
                     "flops_per_launch_avg": flops / max(launches, 1),
                     "whole_step_tflops": round(value * flops_hf / 1e12, 3)}
