@@ -25,14 +25,20 @@ import sys
 
 REF = "/root/reference"
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, REF)          # the reference's `lib` must win over the repo's drop-in `lib`
-sys.path.insert(1, REPO)
+sys.path.insert(0, REPO)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from absolutetrack_amd import arch, synth  # noqa: E402
 from oracle import ref_camera, ref_fk, scenarios, stored_eval  # noqa: E402
+
+# From here on `lib` must be the REFERENCE's package.  The reference's lib/ is a namespace package (no
+# __init__.py) and the repo's drop-in lib/ is a regular one, which would win regardless of sys.path order:
+# take the repo off the path (everything needed from it is already imported) and drop any cached `lib`.
+sys.path[:] = [REF] + [p for p in sys.path if os.path.abspath(p or ".") != REPO]
+for _m in [m for m in sys.modules if m == "lib" or m.startswith("lib.")]:
+    del sys.modules[_m]
 
 GOLD = os.path.join(REPO, "tests", "golden")
 DATA = os.path.join(REPO, "absolutetrack_amd", "data")
