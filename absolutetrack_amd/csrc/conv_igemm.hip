@@ -32,9 +32,40 @@ namespace ut {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float lds_f32;
 
 constexpr int BK = 32;
-constexpr int LDS_ROW = BK + 4;   // floats; 144 B row stride = 9 x 16 B -> conflict-free b128 reads
+// LDS row stride in floats.  Register staging: rows padded to 36 floats (144 B = 9 x 16 B) make the b128
+// fragment reads conflict free.  LDS-DMA staging (buffer_load ... lds) writes 64 lanes x 16 B = 8 whole rows
+// linearly, so rows are unpadded (32 floats) and the 16-byte chunks of a row are XOR-swizzled instead:
+// chunk c of row r lives at position c ^ ((r >> 1) & 7).  The permutation is applied on the SOURCE side
+// (which global chunk a lane fetches); 16-lane read groups then hit 16 distinct 16-byte bank slots.
+template <bool DMA> constexpr int lds_row() { return DMA ? BK : BK + 4; }
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from a buffer (per-lane byte offset, out-of-range -> zeros) straight
+// into LDS at lds_addr + lane*16.  Inline asm on purpose: with the builtin hipcc treats the pending LDS write
+// as aliasing every ds_read and drains vmcnt(0) in front of the fragment reads of the CURRENT buffer, which
+// serialises the whole prefetch.  M0 (the LDS base of the transfer) is written in the statement that uses it
+// and restored; the transfer is invisible to the compiler's wait counting, so dma_wait_all() precedes the
+// barrier that publishes the buffer.
+__device__ __forceinline__ void dma16(u32x4 rsrc, unsigned lds_addr, unsigned voffset) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voffset), "s"(lds_addr), "s"(rsrc)
+      : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ u32x4 make_rsrc_words(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  u32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+  r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xFFFFu);   // stride 0
+  r.z = __builtin_amdgcn_readfirstlane(bytes);
+  r.w = 0x00020000u;
+  return r;
+}
 
 // n / d for 0 <= n < 2^24 via a float reciprocal and one correction step (exact: |error| <= 1 before it)
 __device__ __forceinline__ int fast_div(int n, int d, float inv_d) {
@@ -45,13 +76,14 @@ __device__ __forceinline__ int fast_div(int n, int d, float inv_d) {
   return q;
 }
 
-template <int BM, int BN, int WR, int WC>
+template <int BM, int BN, int WR, int WC, bool DMA>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int tiles_n, int n_tiles) {
   static_assert(WR * WC == 4, "4 waves per workgroup");
   constexpr int MI = BM / WR / 32;   // 32x32 accumulator tiles per wave along M
   constexpr int NI = BN / WC / 32;   // ... along N
   constexpr int AP = BM / 32;        // 16-byte loads per thread per chunk for the A tile
   constexpr int BP = BN / 32;
+  constexpr int LDS_ROW = lds_row<DMA>();
   constexpr int STAGE = (BM + BN) * LDS_ROW;
   constexpr unsigned OOB = 0xFFFFFF00u;
 
@@ -61,8 +93,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WC, wn = wave % WC;
-  const int g = tid & 7;        // which 4-float group of the 32-wide k chunk this thread stages
+  const int g = tid & 7;        // 16-byte position inside the staged LDS row this thread fills
   const int r0 = tid >> 3;      // first tile row this thread stages (then +32 per pass)
+  // which 4-float group of the 32-wide k chunk lands there ((r0 + 32*i) >> 1 & 7 is the same for every pass i)
+  const int gk = DMA ? (g ^ ((r0 >> 1) & 7)) : g;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // provably uniform: LDS-DMA base, M0
   const int fr = lane & 31;     // fragment row (A/B) == accumulator column
   const int fh = lane >> 5;     // k half (A/B) == accumulator row offset 4*fh
 
@@ -84,6 +119,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
 
   const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       p.out, 0, (int)((size_t)M * p.cout_store * sizeof(float)), 0x00020000);
+
+  const u32x4 a_words = make_rsrc_words(p.in, (unsigned)((size_t)p.n_img * p.H * p.W * p.cin * sizeof(float)));
+  const u32x4 b_words = make_rsrc_words(p.w, (unsigned)((size_t)p.cout_pad * p.k_pad * sizeof(float)));
+  const unsigned smem_addr = (unsigned)(unsigned long)(lds_f32*)smem;   // LDS byte address of the staging area
 
   // XCD-aware tile order: workgroups b, b+8, ... share an XCD (and its L2); give each XCD a contiguous
   // run of tiles per round so that neighbouring tiles (shared halo rows, same weights) meet in one L2.
@@ -122,28 +161,38 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
       a_ix[i] = ox * p.stride - p.pad;                                                               \
       a_pix[i] = ((img * p.H + a_iy[i]) * p.W + a_ix[i]) * p.cin;                                    \
     }                                                                                                \
-    b_off = (unsigned)(((tn_ * BN + r0) * p.k_pad + 4 * g) * 4);                                     \
+    b_off = (unsigned)(((tn_ * BN + r0) * p.k_pad + 4 * gk) * 4);                                    \
     /* (slice, tap, channel in slice) of this thread's 4-float group: cslice >= 32 */                \
-    tap = 0; ch = 4 * g; ch_base = 0;                                                                \
+    tap = 0; ch = 4 * gk; ch_base = 0;                                                               \
   }
 
   // The AP+BP 16-byte loads of a chunk are issued in three parts, one in front of each of the first three
   // MFMA groups, instead of in one burst behind the barrier: all waves of a workgroup leave the barrier
   // together, and a burst of 8 loads x 4 waves backs up the address path so that the last wave cannot start
   // its MFMAs (instructions issue in order) until its loads have been accepted.
-#define UT_FETCH_PART(PART)                                                                          \
+#define UT_FETCH_PART(PART, DSTBUF)                                                                  \
   {                                                                                                  \
     int dy = 0, dx = 0;                                                                              \
     if (p.ksize == 3) { dy = (tap * 11) >> 5; dx = tap - 3 * dy; } /* tap/3 for tap < 32 */         \
     const int tap_off = (dy * p.W + dx) * p.cin + ch_base + ch;                                      \
+    const unsigned dst_ = smem_addr + (unsigned)(((DSTBUF) * STAGE + 8 * wave_u * LDS_ROW) * 4);     \
     _Pragma("unroll") for (int i = 0; i < AP; ++i) if (i % 3 == (PART)) {                            \
       const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;                                                \
       const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;                  \
       const unsigned off = ok ? (unsigned)(a_pix[i] + tap_off) * 4u : OOB;                           \
-      UT_DIAG_A(a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off, 0, 0));                \
+      if constexpr (DMA) {                                                                           \
+        UT_DIAG_A(dma16(a_words, dst_ + 32 * i * LDS_ROW * 4, off));                                 \
+      } else {                                                                                       \
+        UT_DIAG_A(a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off, 0, 0));              \
+      }                                                                                              \
     }                                                                                                \
-    _Pragma("unroll") for (int i = 0; i < BP; ++i) if ((i + AP) % 3 == (PART))                       \
-      UT_DIAG_B(b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off + i * b_row_step, 0, 0)); \
+    _Pragma("unroll") for (int i = 0; i < BP; ++i) if ((i + AP) % 3 == (PART)) {                     \
+      if constexpr (DMA) {                                                                           \
+        UT_DIAG_B(dma16(b_words, dst_ + (BM + 32 * i) * LDS_ROW * 4, b_off + i * b_row_step));       \
+      } else {                                                                                       \
+        UT_DIAG_B(b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off + i * b_row_step, 0, 0)); \
+      }                                                                                              \
+    }                                                                                                \
     if ((PART) == 2) { /* advance to the next chunk */                                               \
       b_off += BK * 4;                                                                               \
       ch += BK;                                                                                      \
@@ -151,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
       if (tap >= taps) { tap -= taps; ch_base += p.cslice; }                                         \
     }                                                                                                \
   }
-#define UT_FETCH() { UT_FETCH_PART(0); UT_FETCH_PART(1); UT_FETCH_PART(2); }
+#define UT_FETCH(DSTBUF) { UT_FETCH_PART(0, DSTBUF); UT_FETCH_PART(1, DSTBUF); UT_FETCH_PART(2, DSTBUF); }
 
   // MFMA C layout with the operands as above: lane = pixel (column fr of the 32-pixel fragment), register e =
   // output channel (e&3) + 8*(e>>2) + 4*fh of the 32-channel fragment.  Four consecutive registers are four
@@ -179,7 +228,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
   }
 
 #define UT_STAGE(buf)                                                                                \
-  {                                                                                                  \
+  if constexpr (DMA) {                                                                               \
+    dma_wait_all(); /* every piece of the next chunk has landed before the barrier publishes it */   \
+  } else {                                                                                           \
     float* as_ = smem + (buf) * STAGE;                                                               \
     float* bs_ = as_ + BM * LDS_ROW;                                                                 \
     _Pragma("unroll") for (int i = 0; i < AP; ++i)                                                   \
@@ -198,8 +249,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
   // that consume a set.
 #define UT_READ(SET, buf, q)                                                                         \
   {                                                                                                  \
-    const float* as = smem + (buf) * STAGE + (wm * (MI * 32) + fr) * LDS_ROW + 4 * fh + 8 * (q);     \
-    const float* bs = smem + (buf) * STAGE + BM * LDS_ROW + (wn * (NI * 32) + fr) * LDS_ROW + 4 * fh + 8 * (q); \
+    const int koff_ = DMA ? 4 * ((2 * (q) + fh) ^ ((fr >> 1) & 7)) : 4 * fh + 8 * (q);               \
+    const float* as = smem + (buf) * STAGE + (wm * (MI * 32) + fr) * LDS_ROW + koff_;                \
+    const float* bs = smem + (buf) * STAGE + BM * LDS_ROW + (wn * (NI * 32) + fr) * LDS_ROW + koff_; \
     _Pragma("unroll") for (int i = 0; i < MI; ++i) af##SET[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDS_ROW); \
     _Pragma("unroll") for (int j = 0; j < NI; ++j) bf##SET[j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_ROW); \
   }
@@ -258,9 +310,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     const int steps = rank * p.stagger;       // units of 512 cycles
     for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(8);
   }
+  volatile int* next_slot = reinterpret_cast<volatile int*>(smem + 2 * STAGE);   // one int behind the staging area
   int tile = slot;
   UT_SETUP(tile);
-  UT_FETCH();
+  UT_FETCH(0);
   UT_INIT_LOAD(tile);
   UT_STAGE(0);
   __syncthreads();
@@ -275,15 +328,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NI; ++j) acc[i][j] = init[i][j];
+    if (tid == 0) *next_slot = grid + (int)atomicAdd(p.tile_counter, 1u);   // consumed in the last chunk
 
     // steady state: fetch chunk c+1 (loads stay in flight under the MFMAs), compute chunk c
     for (int c = 0; c + 1 < n_chunks; ++c) {
 #ifndef UT_DIAG_NO_FETCH    /* timing-only ablations for tools/diag (results are wrong with any of them) */
 #ifdef UT_BURST_FETCH
-      UT_FETCH();
+      UT_FETCH(buf ^ 1);
       UT_CHUNK(buf, , , );
 #else
-      UT_CHUNK(buf, UT_FETCH_PART(0), UT_FETCH_PART(1), UT_FETCH_PART(2));
+      UT_CHUNK(buf, UT_FETCH_PART(0, buf ^ 1), UT_FETCH_PART(1, buf ^ 1), UT_FETCH_PART(2, buf ^ 1));
 #endif
 #else
       UT_CHUNK(buf, , , );
@@ -293,14 +347,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
 #ifdef UT_STAMPS
     if (tiles_done == 0) UT_STAMP(2);
 #endif
+    // The next tile comes from a device-wide queue (first round: static XCD-contiguous slots; afterwards one
+    // atomic per workgroup per tile, taken a whole tile ahead by wave 0 and handed over through LDS - the chunk
+    // barriers in between order it).  Dynamic hand-out keeps every CU busy when the tile count is not a multiple
+    // of the resident workgroups; a static stride left up to half of them idle in the last round.
     // last chunk: fetch the first chunk, bias and residual of the NEXT tile under it (without a next tile the
     // staging inside UT_CHUNK rewrites stale registers into the idle buffer: harmless)
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int next = tile + grid;
+    if (n_chunks == 1) __syncthreads();   // no chunk barrier has ordered the queue slot yet
+    const int next = __builtin_amdgcn_readfirstlane(*next_slot);
     const bool has_next = next < n_tiles;
     if (has_next) {
       UT_SETUP(next);
-      UT_FETCH();
+      UT_FETCH(buf ^ 1);
       UT_INIT_LOAD(next);
     }
     UT_CHUNK(buf, , , );
@@ -372,16 +431,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
 #undef UT_MAYBE_STAGE
 }
 
-template <int BM, int BN, int WR, int WC>
+template <int BM, int BN, int WR, int WC, bool DMA>
 static hipError_t launch_cfg(const ConvLaunch& c, hipStream_t s) {
   const int M = c.n_img * c.Ho * c.Wo;
   const int tiles_m = (M + BM - 1) / BM;
   const int tiles_n = (c.cout_store + BN - 1) / BN;
   const int n_tiles = tiles_m * tiles_n;
-  const size_t lds = 2 * (size_t)(BM + BN) * LDS_ROW * sizeof(float);
+  const size_t lds = 2 * (size_t)(BM + BN) * lds_row<DMA>() * sizeof(float) + 16;   // + tile-queue slot
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, DMA>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
@@ -396,21 +455,23 @@ static hipError_t launch_cfg(const ConvLaunch& c, hipStream_t s) {
   // even spacing between ranks is one chunk's MFMA time = (MI*NI) x 16 MFMAs x 64 cycles = (MI*NI) x 2 units
   ConvLaunch cl = c;
   if (c.stagger < 0) cl.stagger = grid > c.num_cu ? (BM / WR / 32) * (BN / WC / 32) * 2 : 0;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC>), dim3(grid), dim3(256), lds, s, cl, tiles_n, n_tiles);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, DMA>), dim3(grid), dim3(256), lds, s, cl, tiles_n, n_tiles);
   return hipGetLastError();
 }
 
 hipError_t launch_conv_igemm(const ConvLaunch& c, hipStream_t s) {
   if (c.res && c.out_nchw) return hipErrorInvalidValue;
+  if (!c.tile_counter) return hipErrorInvalidValue;
   if (c.cin % 4 != 0 || c.cslice < BK || c.k_pad % BK != 0 || c.cout_pad % 128 != 0 || c.ksize * c.ksize > 9 ||
       c.num_cu <= 0)
     return hipErrorInvalidValue;
   // 32-bit byte offsets into the activation / residual tensors
   if ((size_t)c.n_img * c.H * c.W * c.cin * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
   if ((size_t)c.n_img * c.Ho * c.Wo * c.cout_store * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
-  if (c.cout_store <= 32) return launch_cfg<128, 32, 4, 1>(c, s);
-  if (c.cout_store <= 64) return launch_cfg<128, 64, 2, 2>(c, s);
-  return launch_cfg<128, 128, 2, 2>(c, s);
+  static const int dma = [] { const char* e = getenv("UT_CONV_DMA"); return e ? atoi(e) : 7; }();   // bit per tile config
+  if (c.cout_store <= 32) return (dma & 1) ? launch_cfg<128, 32, 4, 1, true>(c, s) : launch_cfg<128, 32, 4, 1, false>(c, s);
+  if (c.cout_store <= 64) return (dma & 2) ? launch_cfg<128, 64, 2, 2, true>(c, s) : launch_cfg<128, 64, 2, 2, false>(c, s);
+  return (dma & 4) ? launch_cfg<128, 128, 2, 2, true>(c, s) : launch_cfg<128, 128, 2, 2, false>(c, s);
 }
 
 }  // namespace ut

@@ -69,6 +69,9 @@ struct ut_context {
   // temporal state
   int slots_cap = 0, slots_used = 0;
   float *mem = nullptr, *prev_ext = nullptr;
+  // tile-queue counters: one word per conv launch of a call, zeroed by one memset at the start of the call
+  unsigned* counters = nullptr;
+  int counter_next = 0;
   // profiling
   bool profiling = false;
   std::vector<ProfEvent> prof;
@@ -275,6 +278,15 @@ int ensure_slots(ut_handle h, int slots, hipStream_t s) {
   return UT_OK;
 }
 
+constexpr int kMaxCounters = 4096;
+
+// zero the tile-queue words used by the conv launches of one API call (stream ordered)
+int begin_call(ut_handle h, hipStream_t s) {
+  h->counter_next = 0;
+  HIPCHK(h, hipMemsetAsync(h->counters, 0, kMaxCounters * sizeof(unsigned), s));
+  return UT_OK;
+}
+
 int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, float* out, int n_img, int H, int W,
              bool relu, bool nchw, hipStream_t s) {
   ut::ConvLaunch c{};
@@ -287,6 +299,11 @@ int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, fl
   c.ksize = cw.ksize; c.stride = cw.stride; c.pad = cw.pad;
   c.relu = relu; c.out_nchw = nchw;
   c.num_cu = h->num_cu; c.persist_limit = h->persist_limit; c.stagger = h->stagger;
+  if (h->counter_next >= kMaxCounters) {   // recycle: stream order puts the memset behind the earlier launches
+    int rc0 = begin_call(h, s);
+    if (rc0) return rc0;
+  }
+  c.tile_counter = h->counters + h->counter_next++;
   ProfEvent pe{};
   if (h->profiling) {
     HIPCHK(h, hipEventCreate(&pe.a));
@@ -351,6 +368,7 @@ int ut_create(int device, const float* blob, size_t n_floats, ut_handle* out) {
       b[o] = (float)(((double)sb[o] - (double)sbn.m[o]) * s + (double)sbn.b[o]);
     }
     if ((rc = upload(h, w, &h->stem_w)) || (rc = upload(h, b, &h->stem_b))) break;
+    { float* cnt = nullptr; if ((rc = dev_alloc(h, &cnt, kMaxCounters))) break; h->counters = (unsigned*)cnt; }
     // ResNet layers "2352", planes 32/64/128/256, strides 1/2/2/2 (lib/models/backbone_resnet.py:168-192)
     const int nb[4] = {2, 3, 5, 2}, planes[4] = {32, 64, 128, 256}, strides[4] = {1, 2, 2, 2};
     int cin = 32, bi = 0;
@@ -456,6 +474,7 @@ int ut_backbone(ut_handle h, const float* crops, int n_crops, float* feat, void*
   if ((rc = ensure_backbone_ws(h, chunk))) return rc;
   const int pass_b = n_crops < PHASE_B_MAX ? n_crops : PHASE_B_MAX;
   if ((rc = ensure_phase_b_ws(h, pass_b))) return rc;
+  if ((rc = begin_call(h, s))) return rc;
   for (int base = 0; base < n_crops; base += pass_b) {
     const int nb = n_crops - base < pass_b ? n_crops - base : pass_b;
     // ---- phase A: stem + layer1 (48x48x32) + layer2 (24x24x64), `chunk` crops per pass
@@ -512,6 +531,7 @@ int ut_fuse_temporal_regress(ut_handle h, const float* feat, const float* intrin
   if ((rc = ensure_head_ws(h, n_samples, n_skel))) return rc;
   if ((rc = ensure_slots(h, n_slots, s))) return rc;
   if (n_slots > h->slots_used) h->slots_used = n_slots;
+  if ((rc = begin_call(h, s))) return rc;
   ut::HeadArgs a{};
   a.feat = feat; a.intrinsics = intrinsics; a.extrinsics = extrinsics; a.sample_range = sample_range;
   a.memory_idx = memory_idx; a.use_memory = use_memory; a.hand_idx = hand_idx; a.n_samples = n_samples;

@@ -9,5 +9,9 @@ extern "C" int conv_diag(const float* in, const float* w, const float* bias, con
   c.cout_store = cout; c.cout_pad = (cout + 127) / 128 * 128; c.k_total = k_total; c.k_pad = k_total;
   c.cslice = cin % 32 == 0 ? 32 : cin; c.ksize = 3; c.stride = 1; c.pad = 1; c.relu = 1; c.out_nchw = 0;
   c.num_cu = 256; c.persist_limit = 0; c.stagger = -1; c.stamps = stamps;
+  static unsigned* cnt = nullptr;
+  if (!cnt) (void)hipMalloc((void**)&cnt, 4);
+  (void)hipMemsetAsync(cnt, 0, 4, 0);
+  c.tile_counter = cnt;
   return (int)ut::launch_conv_igemm(c, 0);
 }
