@@ -468,7 +468,11 @@ hipError_t launch_conv_igemm(const ConvLaunch& c, hipStream_t s) {
   // 32-bit byte offsets into the activation / residual tensors
   if ((size_t)c.n_img * c.H * c.W * c.cin * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
   if ((size_t)c.n_img * c.Ho * c.Wo * c.cout_store * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
+  static const int use_patch = [] { const char* e = getenv("UT_CONV_PATCH"); return e ? atoi(e) : 1; }();
+  if (use_patch && conv_patch_applicable(c)) return launch_conv_patch(c, s);
   static const int dma = [] { const char* e = getenv("UT_CONV_DMA"); return e ? atoi(e) : 7; }();   // bit per tile config
+  static const int big32 = [] { const char* e = getenv("UT_CONV_BIG32"); return e ? atoi(e) : 0; }();
+  if (c.cout_store <= 32 && big32) return launch_cfg<256, 32, 4, 1, true>(c, s);
   if (c.cout_store <= 32) return (dma & 1) ? launch_cfg<128, 32, 4, 1, true>(c, s) : launch_cfg<128, 32, 4, 1, false>(c, s);
   if (c.cout_store <= 64) return (dma & 2) ? launch_cfg<128, 64, 2, 2, true>(c, s) : launch_cfg<128, 64, 2, 2, false>(c, s);
   return (dma & 4) ? launch_cfg<128, 128, 2, 2, true>(c, s) : launch_cfg<128, 128, 2, 2, false>(c, s);

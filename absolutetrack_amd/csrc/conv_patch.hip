@@ -1,0 +1,248 @@
+// 3x3 / stride-1 / 32->32-channel convolution (the four convolutions of ResNet layer1,
+// lib/models/backbone_resnet.py:56-72 at 48x48x32) with the input HALO PATCH resident in LDS.
+//
+// In the generic implicit GEMM (conv_igemm.hip) every one of the 9 taps re-stages the same pixels through
+// LDS: with only 32 output channels that is 6.5 MAC per staged byte and the global->LDS path (not the MFMA
+// pipe, not latency) is what bounds it at ~60 % of the fp32-MFMA rate.  Here one workgroup (8 waves, one
+// per CU) owns a 16x16-pixel output tile: the 18x18x32 input patch is brought into LDS ONCE by LDS-DMA
+// (double buffered: the next tile's patch streams in under the current tile's MFMAs), all 9x32x32 weights stay
+// resident in LDS for the life of the (persistent) workgroup, and the 9 taps read shifted windows of the patch.
+// Global->LDS traffic drops from 180 KB to 41 KB per 256 output pixels; there is no barrier inside a tile's
+// 144-MFMA stream, one per tile.
+//
+// MFMA operand roles as in conv_igemm.hip: weights = "A" (rows = output channel), pixels = "B" (columns), so a
+// lane owns one pixel and accumulator register quads are 4 consecutive channels (16-byte NHWC accesses).
+// LDS rows are 128 B (32 floats) with the 16-byte chunks XOR-swizzled by ((row >> 1) & 7), applied on the source
+// side of the DMA; rows are "pixel of the patch" resp. "(tap, output channel)".
+#include "ut_kernels.h"
+
+namespace ut {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float lds_f32p;
+
+namespace {
+constexpr int T = 16;                       // output tile is T x T pixels
+constexpr int PW = T + 2;                   // patch width / height
+constexpr int PPIX = PW * PW;               // 324 patch pixels
+constexpr int PROWS = (PPIX + 7) / 8 * 8;   // 328: DMA pieces cover whole 8-row groups
+constexpr int C = 32;
+constexpr int W_FLOATS = 9 * C * C;         // 9216
+constexpr int P_FLOATS = PROWS * C;         // 10496
+constexpr int PATCH_INSTR = PROWS / 8;      // 41 wave-level DMA instructions per patch
+constexpr int W_INSTR = 9 * C / 8;          // 36
+constexpr unsigned OOBP = 0xFFFFFF00u;
+
+__device__ __forceinline__ void dma16p(u32x4 rsrc, unsigned lds_addr, unsigned voffset) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voffset), "s"(lds_addr), "s"(rsrc)
+      : "memory");
+}
+__device__ __forceinline__ u32x4 rsrc_words(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  u32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+  r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xFFFFu);
+  r.z = __builtin_amdgcn_readfirstlane(bytes);
+  r.w = 0x00020000u;
+  return r;
+}
+}  // namespace
+
+__global__ __launch_bounds__(512) void conv3x3_c32_patch_kernel(ConvLaunch p, int tiles_x, int tiles_per_img, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* w_lds = smem;                                  // [9*32 rows][32]
+  float* patch0 = smem + W_FLOATS;                      // 2 x [328 rows][32]
+  volatile int* queue_slot = reinterpret_cast<volatile int*>(smem + W_FLOATS + 2 * P_FLOATS);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
+  const int fr = lane & 31, fh = lane >> 5;
+  const int H = p.H, W = p.W;
+  const int M = p.n_img * H * W;
+  const unsigned smem_addr = (unsigned)(unsigned long)(lds_f32p*)smem;
+
+  const u32x4 in_words = rsrc_words(p.in, (unsigned)((size_t)M * C * sizeof(float)));
+  const u32x4 w_words = rsrc_words(p.w, (unsigned)((size_t)p.cout_pad * p.k_pad * sizeof(float)));
+  const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.res ? p.res : p.bias), 0, p.res ? (int)((size_t)M * C * sizeof(float)) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t o_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((size_t)M * C * sizeof(float)), 0x00020000);
+
+  // ---- weights -> LDS once (row = tap*32 + n, swizzle by n)
+  for (int k = wave; k < W_INSTR; k += 8) {
+    const int e = k * 64 + lane;
+    const int row = e >> 3, cpos = e & 7;
+    const int n = row & 31, tap = row >> 5;
+    const int c4 = cpos ^ ((n >> 1) & 7);
+    dma16p(w_words, smem_addr + (unsigned)(k * 64 * 16), (unsigned)((n * p.k_pad + tap * C + 4 * c4) * 4));
+  }
+
+  // ---- per-lane constants of the patch DMA: which patch pixel / channel chunk each of my pieces is
+  constexpr int MAXP = (PATCH_INSTR + 7) / 8;   // 6 instructions per wave at most
+  int pc_py[MAXP], pc_px[MAXP], pc_c4[MAXP];
+#pragma unroll
+  for (int j = 0; j < MAXP; ++j) {
+    const int k = wave + 8 * j;
+    const int e = k * 64 + lane;
+    const int pidx = e >> 3, cpos = e & 7;
+    const int py = (pidx * 3641) >> 16;       // pidx / 18 for pidx < 400
+    pc_py[j] = (k < PATCH_INSTR && pidx < PPIX) ? py : -1000;
+    pc_px[j] = pidx - py * PW;
+    pc_c4[j] = cpos ^ ((pidx >> 1) & 7);
+  }
+
+  auto tile_origin = [&](int tile, int& img, int& y0, int& x0) {
+    img = tile / tiles_per_img;
+    const int r = tile - img * tiles_per_img;
+    const int ty = r / tiles_x;
+    y0 = ty * T;
+    x0 = (r - ty * tiles_x) * T;
+  };
+
+  auto issue_patch = [&](int tile, int buf) {
+    int img, y0, x0;
+    tile_origin(tile, img, y0, x0);
+    const unsigned dst = smem_addr + (unsigned)((W_FLOATS + buf * P_FLOATS) * 4);
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+      const int k = wave + 8 * j;
+      if (k < PATCH_INSTR) {     // wave-uniform
+        const int gy = y0 - 1 + pc_py[j], gx = x0 - 1 + pc_px[j];
+        const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const unsigned off = ok ? (unsigned)((((img * H + gy) * W + gx) * C + 4 * pc_c4[j]) * 4) : OOBP;
+        dma16p(in_words, dst + (unsigned)(k * 64 * 16), off);
+      }
+    }
+  };
+
+  // my output pixel inside the tile and its position in the patch (tap 0,0 = one up, one left)
+  const int ly = 2 * wave + (fr >> 4), lx = fr & 15;
+  const int pbase = ly * PW + lx;
+  // weight fragment: row = tap*32 + fr (output channel fr), chunk (2q+fh) swizzled by fr
+  int w_off[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) w_off[q] = fr * C + 4 * ((2 * q + fh) ^ ((fr >> 1) & 7));
+
+  f32x16 init;
+  auto init_load = [&](int tile) {
+    int img, y0, x0;
+    tile_origin(tile, img, y0, x0);
+    const int m = (img * H + y0 + ly) * W + x0 + lx;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int n = 8 * g4 + 4 * fh;
+      const float4 bias = *reinterpret_cast<const float4*>(p.bias + n);
+      const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, (unsigned)(m * C + n) * 4u, 0, 0);
+      init[4 * g4 + 0] = bias.x + __uint_as_float(r.x);
+      init[4 * g4 + 1] = bias.y + __uint_as_float(r.y);
+      init[4 * g4 + 2] = bias.z + __uint_as_float(r.z);
+      init[4 * g4 + 3] = bias.w + __uint_as_float(r.w);
+    }
+  };
+
+  const int grid = gridDim.x;
+  int tile = blockIdx.x;
+  issue_patch(tile, 0);
+  init_load(tile);
+  if (tid == 0) queue_slot[2] = grid + (int)atomicAdd(p.tile_counter, 1u);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int next = __builtin_amdgcn_readfirstlane(queue_slot[2]);
+  int cur = 0;
+
+  for (;;) {
+    const bool has_next = next < n_tiles;
+    f32x16 acc = init;
+    // the tile after next; two slots alternate so that a wave still reading one is never overrun (the
+    // end-of-tile barrier separates a slot's read from its next write)
+    if (tid == 0) queue_slot[cur] = grid + (int)atomicAdd(p.tile_counter, 1u);
+    if (has_next) {
+      issue_patch(next, cur ^ 1);     // streams in under this tile's MFMAs
+      init_load(next);
+    }
+
+    const float* patch = patch0 + cur * P_FLOATS;
+    // 9 taps x 4 k-groups, fragments double buffered in registers
+    float4 wfX, pfX, wfY, pfY;
+#define UTP_READ(SET, TAP, Q)                                                                        \
+  {                                                                                                  \
+    const int pidx_ = pbase + ((TAP) / 3) * PW + ((TAP) % 3);                                        \
+    pf##SET = *reinterpret_cast<const float4*>(patch + pidx_ * C + 4 * ((2 * (Q) + fh) ^ ((pidx_ >> 1) & 7))); \
+    wf##SET = *reinterpret_cast<const float4*>(w_lds + (TAP) * C * C + w_off[Q]);                    \
+  }
+#define UTP_MFMA(SET)                                                                                \
+  {                                                                                                  \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf##SET.x, pf##SET.x, acc, 0, 0, 0);                  \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf##SET.y, pf##SET.y, acc, 0, 0, 0);                  \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf##SET.z, pf##SET.z, acc, 0, 0, 0);                  \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf##SET.w, pf##SET.w, acc, 0, 0, 0);                  \
+  }
+    UTP_READ(X, 0, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      UTP_READ(Y, tap, 1); __builtin_amdgcn_sched_barrier(0); UTP_MFMA(X); __builtin_amdgcn_sched_barrier(0);
+      UTP_READ(X, tap, 2); __builtin_amdgcn_sched_barrier(0); UTP_MFMA(Y); __builtin_amdgcn_sched_barrier(0);
+      UTP_READ(Y, tap, 3); __builtin_amdgcn_sched_barrier(0); UTP_MFMA(X); __builtin_amdgcn_sched_barrier(0);
+      if (tap < 8) { UTP_READ(X, tap + 1, 0); }
+      __builtin_amdgcn_sched_barrier(0); UTP_MFMA(Y); __builtin_amdgcn_sched_barrier(0);
+    }
+#undef UTP_READ
+#undef UTP_MFMA
+
+    // epilogue: (ReLU) + 4 x 16-byte stores per lane
+    {
+      int img, y0, x0;
+      tile_origin(tile, img, y0, x0);
+      const int m = (img * H + y0 + ly) * W + x0 + lx;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int n = 8 * g4 + 4 * fh;
+        u32x4 pk;
+        float v0 = acc[4 * g4], v1 = acc[4 * g4 + 1], v2 = acc[4 * g4 + 2], v3 = acc[4 * g4 + 3];
+        if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+        pk.x = __float_as_uint(v0); pk.y = __float_as_uint(v1); pk.z = __float_as_uint(v2); pk.w = __float_as_uint(v3);
+        __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, (unsigned)(m * C + n) * 4u, 0, 0);
+      }
+    }
+    if (!has_next) break;
+    // the next patch has landed (my pieces) and every wave is done reading the current one
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int next2 = __builtin_amdgcn_readfirstlane(queue_slot[cur]);
+    tile = next;
+    next = next2;
+    cur ^= 1;
+  }
+}
+
+bool conv_patch_applicable(const ConvLaunch& c) {
+  return c.ksize == 3 && c.stride == 1 && c.pad == 1 && c.cin == C && c.cout_store == C && c.cslice == C &&
+         c.k_pad == 9 * C && c.H % T == 0 && c.W % T == 0 && !c.out_nchw && c.H == c.Ho && c.W == c.Wo &&
+         (size_t)c.n_img * c.H * c.W * C * sizeof(float) < 0x7FFFFF00ull;
+}
+
+hipError_t launch_conv_patch(const ConvLaunch& c, hipStream_t s) {
+  if (!conv_patch_applicable(c) || !c.tile_counter || c.num_cu <= 0) return hipErrorInvalidValue;
+  const int tiles_x = c.W / T, tiles_per_img = tiles_x * (c.H / T);
+  const int n_tiles = c.n_img * tiles_per_img;
+  const size_t lds = (size_t)(W_FLOATS + 2 * P_FLOATS) * sizeof(float) + 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c32_patch_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  int grid = c.num_cu;           // one 512-thread workgroup per CU (LDS: 121 KB)
+  if (grid > n_tiles) grid = n_tiles;
+  hipLaunchKernelGGL(conv3x3_c32_patch_kernel, dim3(grid), dim3(512), lds, s, c, tiles_x, tiles_per_img, n_tiles);
+  return hipGetLastError();
+}
+
+}  // namespace ut

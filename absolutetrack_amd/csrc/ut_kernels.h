@@ -37,6 +37,9 @@ struct ConvLaunch {
 };
 
 hipError_t launch_conv_igemm(const ConvLaunch& c, hipStream_t s);
+// 3x3 stride-1 32->32 channel convs with the halo patch resident in LDS (conv_patch.hip)
+bool conv_patch_applicable(const ConvLaunch& c);
+hipError_t launch_conv_patch(const ConvLaunch& c, hipStream_t s);
 
 // stem: conv3x3(1->32,pad 1)+BN+ReLU+maxpool2 ; crops [n,96,96] -> NHWC [n,48,48,32]
 hipError_t launch_stem(const float* crops, const float* w /*[32][9]*/, const float* bias /*[32]*/,

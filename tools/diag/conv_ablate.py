@@ -27,7 +27,7 @@ variants = [("baseline", []), ("no_A_loads", ["-DUT_DIAG_NO_A"]), ("no_B_loads",
 for name, flags in variants:
     so = "/tmp/libconvdiag_" + "".join(ch if ch.isalnum() else "_" for ch in name) + ".so"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DUT_STAMPS",
-                           *flags, "-o", so, os.path.join(CSRC, "conv_igemm.hip"),
+                           *flags, "-o", so, os.path.join(CSRC, "conv_igemm.hip"), os.path.join(CSRC, "conv_patch.hip"),
                            os.path.join(ROOT, "tools", "diag", "conv_diag_entry.hip"), "-I", CSRC])
     lib = ctypes.CDLL(so)
     lib.conv_diag.restype = ctypes.c_int

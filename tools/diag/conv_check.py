@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 CSRC = os.path.join(ROOT, "absolutetrack_amd", "csrc")
 OUT = "/tmp/libconvdiag_chk.so"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DUT_STAMPS",
-                       "-o", OUT, os.path.join(CSRC, "conv_igemm.hip"), os.path.join(ROOT, "tools", "diag", "conv_diag_entry.hip"), "-I", CSRC])
+                       "-o", OUT, os.path.join(CSRC, "conv_igemm.hip"), os.path.join(CSRC, "conv_patch.hip"), os.path.join(ROOT, "tools", "diag", "conv_diag_entry.hip"), "-I", CSRC])
 lib = ctypes.CDLL(OUT)
 cin, cout, hw, n_img = (int(a) for a in sys.argv[1:5])
 use_res = len(sys.argv) > 5
