@@ -328,7 +328,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NI; ++j) acc[i][j] = init[i][j];
-    if (tid == 0) *next_slot = grid + (int)atomicAdd(p.tile_counter, 1u);   // consumed in the last chunk
+    // the returning atomic is ISSUED here; its result goes to the LDS slot one chunk later (waiting for it here
+    // would hold wave 0, and with it every chunk barrier of the workgroup, for a memory round trip per tile)
+    unsigned ticket = 0;
+    if (tid == 0) ticket = atomicAdd(p.tile_counter, 1u);
 
     // steady state: fetch chunk c+1 (loads stay in flight under the MFMAs), compute chunk c
     for (int c = 0; c + 1 < n_chunks; ++c) {
@@ -343,6 +346,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
       UT_CHUNK(buf, , , );
 #endif
       buf ^= 1;
+      if (c == 0 && tid == 0) *next_slot = grid + (int)ticket;   // ordered before its read by the later chunk barriers
     }
 #ifdef UT_STAMPS
     if (tiles_done == 0) UT_STAMP(2);
@@ -354,7 +358,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     // last chunk: fetch the first chunk, bias and residual of the NEXT tile under it (without a next tile the
     // staging inside UT_CHUNK rewrites stale registers into the idle buffer: harmless)
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    if (n_chunks == 1) __syncthreads();   // no chunk barrier has ordered the queue slot yet
+    if (n_chunks <= 2) {                  // too few chunk barriers to order the queue slot: do it explicitly
+      if (n_chunks == 1 && tid == 0) *next_slot = grid + (int)ticket;
+      __syncthreads();
+    }
     const int next = __builtin_amdgcn_readfirstlane(*next_slot);
     const bool has_next = next < n_tiles;
     if (has_next) {

@@ -57,7 +57,17 @@ __global__ __launch_bounds__(512) void conv3x3_c32_patch_kernel(ConvLaunch p, in
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* w_lds = smem;                                  // [9*32 rows][32]
   float* patch0 = smem + W_FLOATS;                      // 2 x [328 rows][32]
-  volatile int* queue_slot = reinterpret_cast<volatile int*>(smem + W_FLOATS + 2 * P_FLOATS);
+  // tile-queue hand-over words behind the patches.  Accessed with explicit DS instructions: a `volatile int*`
+  // into LDS is compiled as a FLAT load, which counts on vmcnt and would wait for the tile's stores.
+  const unsigned slot_addr0 = (unsigned)(unsigned long)(lds_f32p*)smem + (unsigned)((W_FLOATS + 2 * P_FLOATS) * 4);
+  auto slot_write = [&](int idx, int v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(slot_addr0 + 4u * (unsigned)idx), "v"(v) : "memory");
+  };
+  auto slot_read = [&](int idx) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(slot_addr0 + 4u * (unsigned)idx) : "memory");
+    return __builtin_amdgcn_readfirstlane(v);
+  };
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -150,18 +160,22 @@ __global__ __launch_bounds__(512) void conv3x3_c32_patch_kernel(ConvLaunch p, in
   int tile = blockIdx.x;
   issue_patch(tile, 0);
   init_load(tile);
-  if (tid == 0) queue_slot[2] = grid + (int)atomicAdd(p.tile_counter, 1u);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0) slot_write(2, grid + (int)atomicAdd(p.tile_counter, 1u));
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
-  int next = __builtin_amdgcn_readfirstlane(queue_slot[2]);
+  int next = slot_read(2);
   int cur = 0;
 
+  f32x16 ready = init;      // bias + residual of the tile about to be computed, already waited for
   for (;;) {
     const bool has_next = next < n_tiles;
-    f32x16 acc = init;
+    f32x16 acc = ready;
     // the tile after next; two slots alternate so that a wave still reading one is never overrun (the
     // end-of-tile barrier separates a slot's read from its next write)
-    if (tid == 0) queue_slot[cur] = grid + (int)atomicAdd(p.tile_counter, 1u);
+    // (the returning atomic is ISSUED here and consumed after the MFMA stream: waiting for it here would
+    // hold wave 0 - and with it the end-of-tile barrier - for a full memory round trip per tile)
+    unsigned ticket = 0;
+    if (tid == 0) ticket = atomicAdd(p.tile_counter, 1u);
     if (has_next) {
       issue_patch(next, cur ^ 1);     // streams in under this tile's MFMAs
       init_load(next);
@@ -195,6 +209,15 @@ __global__ __launch_bounds__(512) void conv3x3_c32_patch_kernel(ConvLaunch p, in
 #undef UTP_READ
 #undef UTP_MFMA
 
+    // The next patch (my pieces) and the next tile's residual were requested a whole tile ago: drain the
+    // counter BEFORE the stores below - vmcnt counts stores too, and waiting for them at the barrier would
+    // stall every wave for a full write round trip per tile.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) slot_write(cur, grid + (int)ticket);
+    // take the next tile's bias+residual out of the load registers HERE, so that the compiler's own wait for
+    // those loads also sits in front of the stores (an opaque use pins the copy to this point)
+    ready = init;
+    asm volatile("" : "+v"(ready));
     // epilogue: (ReLU) + 4 x 16-byte stores per lane
     {
       int img, y0, x0;
@@ -211,10 +234,10 @@ __global__ __launch_bounds__(512) void conv3x3_c32_patch_kernel(ConvLaunch p, in
       }
     }
     if (!has_next) break;
-    // the next patch has landed (my pieces) and every wave is done reading the current one
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int next2 = __builtin_amdgcn_readfirstlane(queue_slot[cur]);
+    // every wave's pieces of the next patch have landed and everyone is done reading the current one
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
+    __builtin_amdgcn_s_barrier();
+    const int next2 = slot_read(cur);
     tile = next;
     next = next2;
     cur ^= 1;
