@@ -120,6 +120,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
   const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       p.out, 0, (int)((size_t)M * p.cout_store * sizeof(float)), 0x00020000);
 
+  // tile-queue ticket: a straight-line buffer atomic (only thread 0 has an in-range offset, the range check
+  // drops the others) whose result is awaited where it is used, not where it is issued
+  const __amdgpu_buffer_rsrc_t q_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.tile_counter, 0, 4, 0x00020000);
+  const unsigned q_off = tid == 0 ? 0u : OOB;
   const u32x4 a_words = make_rsrc_words(p.in, (unsigned)((size_t)p.n_img * p.H * p.W * p.cin * sizeof(float)));
   const u32x4 b_words = make_rsrc_words(p.w, (unsigned)((size_t)p.cout_pad * p.k_pad * sizeof(float)));
   const unsigned smem_addr = (unsigned)(unsigned long)(lds_f32*)smem;   // LDS byte address of the staging area
@@ -135,7 +139,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
   unsigned b_off;
   int tap, ch, ch_base;
   u32x4 a_reg[AP], b_reg[BP];
-  f32x16 init[MI][NI];          // bias (+ residual) of the tile being fetched
+  // bias and residual of the tile being fetched: requested a tile ahead, combined only when that tile starts
+  // (arithmetic at request time would make the compiler wait for the loads in front of the MFMAs)
+  u32x4 res_raw[MI][NI][4];
+  float4 bias_raw[NI][4];
 
 #ifdef UT_DIAG_NO_A   /* timing-only ablations (tools/diag) */
 #define UT_DIAG_A(x) asm volatile("" ::"v"(off))
@@ -208,24 +215,32 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
 #define UT_INIT_LOAD(TILE)                                                                           \
   {                                                                                                  \
     const int tm_ = (TILE) / tiles_n, tn_ = (TILE) - tm_ * tiles_n;                                  \
+    _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                   \
+      _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4)                                               \
+        bias_raw[j][g4] = *reinterpret_cast<const float4*>(                                          \
+            p.bias + tn_ * BN + wn * (NI * 32) + j * 32 + 8 * g4 + 4 * fh); /* padded to cout_pad */ \
     _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                 \
       const int m = tm_ * BM + wm * (MI * 32) + i * 32 + fr;                                         \
       const bool m_ok = m < M;                                                                       \
       _Pragma("unroll") for (int j = 0; j < NI; ++j) {                                               \
         _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4) {                                           \
           const int n = tn_ * BN + wn * (NI * 32) + j * 32 + 8 * g4 + 4 * fh;                        \
-          const float4 bias = *reinterpret_cast<const float4*>(p.bias + n); /* padded to cout_pad */ \
           const unsigned off = (m_ok && n < p.cout_store) ? (unsigned)(m * p.cout_store + n) * 4u : OOB; \
-          /* NB: __builtin_bit_cast on a vector ELEMENT (r.y) miscompiles to a splat of r.x (ROCm 7.2) */  \
-          const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0);                  \
-          init[i][j][4 * g4 + 0] = bias.x + __uint_as_float(r.x);                          \
-          init[i][j][4 * g4 + 1] = bias.y + __uint_as_float(r.y);                          \
-          init[i][j][4 * g4 + 2] = bias.z + __uint_as_float(r.z);                          \
-          init[i][j][4 * g4 + 3] = bias.w + __uint_as_float(r.w);                          \
+          res_raw[i][j][g4] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0);              \
         }                                                                                            \
       }                                                                                              \
     }                                                                                                \
   }
+  /* NB: __builtin_bit_cast on a vector ELEMENT (r.y) miscompiles to a splat of r.x (ROCm 7.2): __uint_as_float */
+#define UT_INIT_COMBINE()                                                                            \
+  _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                     \
+    _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                   \
+      _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4) {                                             \
+        acc[i][j][4 * g4 + 0] = bias_raw[j][g4].x + __uint_as_float(res_raw[i][j][g4].x);            \
+        acc[i][j][4 * g4 + 1] = bias_raw[j][g4].y + __uint_as_float(res_raw[i][j][g4].y);            \
+        acc[i][j][4 * g4 + 2] = bias_raw[j][g4].z + __uint_as_float(res_raw[i][j][g4].z);            \
+        acc[i][j][4 * g4 + 3] = bias_raw[j][g4].w + __uint_as_float(res_raw[i][j][g4].w);            \
+      }
 
 #define UT_STAGE(buf)                                                                                \
   if constexpr (DMA) {                                                                               \
@@ -324,14 +339,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
   float4 afX[MI], bfX[NI], afY[MI], bfY[NI];
   UT_READ(X, 0, 0);
   for (;;) {
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) acc[i][j] = init[i][j];
+    UT_INIT_COMBINE();
     // the returning atomic is ISSUED here; its result goes to the LDS slot one chunk later (waiting for it here
     // would hold wave 0, and with it every chunk barrier of the workgroup, for a memory round trip per tile)
-    unsigned ticket = 0;
-    if (tid == 0) ticket = atomicAdd(p.tile_counter, 1u);
+    const int ticket = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, q_rsrc, q_off, 0, 0);
 
     // steady state: fetch chunk c+1 (loads stay in flight under the MFMAs), compute chunk c
     for (int c = 0; c + 1 < n_chunks; ++c) {
@@ -346,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
       UT_CHUNK(buf, , , );
 #endif
       buf ^= 1;
-      if (c == 0 && tid == 0) *next_slot = grid + (int)ticket;   // ordered before its read by the later chunk barriers
+      if (c == 0 && tid == 0) *next_slot = grid + ticket;   // ordered before its read by the later chunk barriers
     }
 #ifdef UT_STAMPS
     if (tiles_done == 0) UT_STAMP(2);
@@ -359,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     // staging inside UT_CHUNK rewrites stale registers into the idle buffer: harmless)
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     if (n_chunks <= 2) {                  // too few chunk barriers to order the queue slot: do it explicitly
-      if (n_chunks == 1 && tid == 0) *next_slot = grid + (int)ticket;
+      if (n_chunks == 1 && tid == 0) *next_slot = grid + ticket;
       __syncthreads();
     }
     const int next = __builtin_amdgcn_readfirstlane(*next_slot);
@@ -429,6 +440,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
 #undef UT_FETCH
 #undef UT_FETCH_PART
 #undef UT_INIT_LOAD
+#undef UT_INIT_COMBINE
 #undef UT_STAGE
 #undef UT_CHUNK
 #undef UT_READ

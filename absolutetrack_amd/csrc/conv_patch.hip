@@ -107,27 +107,31 @@ __global__ __launch_bounds__(512) void conv3x3_c32_patch_kernel(ConvLaunch p, in
     pc_c4[j] = cpos ^ ((pidx >> 1) & 7);
   }
 
-  auto tile_origin = [&](int tile, int& img, int& y0, int& x0) {
-    img = tile / tiles_per_img;
-    const int r = tile - img * tiles_per_img;
-    const int ty = r / tiles_x;
+  // tile -> (first output pixel row index of the image, y0, x0); scalar float-reciprocal division (tile counts
+  // are far below 2^24)
+  const float inv_tpi = 1.0f / (float)tiles_per_img, inv_tx = 1.0f / (float)tiles_x;
+  auto tile_origin = [&](int tile, int& row0, int& y0, int& x0) {
+    int img = (int)((float)tile * inv_tpi);
+    int r = tile - img * tiles_per_img;
+    if (r < 0) { --img; r += tiles_per_img; }
+    if (r >= tiles_per_img) { ++img; r -= tiles_per_img; }
+    int ty = (int)((float)r * inv_tx);
+    int c = r - ty * tiles_x;
+    if (c < 0) { --ty; c += tiles_x; }
+    if (c >= tiles_x) { ++ty; c -= tiles_x; }
+    row0 = img * H;
     y0 = ty * T;
-    x0 = (r - ty * tiles_x) * T;
+    x0 = c * T;
   };
 
-  auto issue_patch = [&](int tile, int buf) {
-    int img, y0, x0;
-    tile_origin(tile, img, y0, x0);
-    const unsigned dst = smem_addr + (unsigned)((W_FLOATS + buf * P_FLOATS) * 4);
-#pragma unroll
-    for (int j = 0; j < MAXP; ++j) {
-      const int k = wave + 8 * j;
-      if (k < PATCH_INSTR) {     // wave-uniform
-        const int gy = y0 - 1 + pc_py[j], gx = x0 - 1 + pc_px[j];
-        const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-        const unsigned off = ok ? (unsigned)((((img * H + gy) * W + gx) * C + 4 * pc_c4[j]) * 4) : OOBP;
-        dma16p(in_words, dst + (unsigned)(k * 64 * 16), off);
-      }
+  // one wave-level DMA instruction (j-th of this wave) of the patch of the tile with origin (row0, y0, x0)
+  auto issue_piece = [&](int j, int row0, int y0, int x0, int buf) {
+    const int k = wave + 8 * j;
+    if (k < PATCH_INSTR) {     // wave-uniform
+      const int gy = y0 - 1 + pc_py[j], gx = x0 - 1 + pc_px[j];
+      const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const unsigned off = ok ? (unsigned)((((row0 + gy) * W + gx) * C + 4 * pc_c4[j]) * 4) : OOBP;
+      dma16p(in_words, smem_addr + (unsigned)((W_FLOATS + buf * P_FLOATS) * 4 + k * 64 * 16), off);
     }
   };
 
@@ -139,50 +143,76 @@ __global__ __launch_bounds__(512) void conv3x3_c32_patch_kernel(ConvLaunch p, in
 #pragma unroll
   for (int q = 0; q < 4; ++q) w_off[q] = fr * C + 4 * ((2 * q + fh) ^ ((fr >> 1) & 7));
 
-  f32x16 init;
-  auto init_load = [&](int tile) {
-    int img, y0, x0;
-    tile_origin(tile, img, y0, x0);
-    const int m = (img * H + y0 + ly) * W + x0 + lx;
+  // bias and residual of a tile are REQUESTED a tile ahead and only combined when needed: any arithmetic on
+  // them at request time would make the compiler wait for the loads in front of the MFMAs
+  u32x4 res_raw[4];
+  float4 bias_raw[4];
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) bias_raw[g4] = *reinterpret_cast<const float4*>(p.bias + 8 * g4 + 4 * fh);
+  auto init_load = [&](int row0, int y0, int x0) {
+    const int m = (row0 + y0 + ly) * W + x0 + lx;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+      res_raw[g4] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, (unsigned)(m * C + 8 * g4 + 4 * fh) * 4u, 0, 0);
+  };
+  auto init_combine = [&]() {
+    f32x16 v;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
-      const int n = 8 * g4 + 4 * fh;
-      const float4 bias = *reinterpret_cast<const float4*>(p.bias + n);
-      const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, (unsigned)(m * C + n) * 4u, 0, 0);
-      init[4 * g4 + 0] = bias.x + __uint_as_float(r.x);
-      init[4 * g4 + 1] = bias.y + __uint_as_float(r.y);
-      init[4 * g4 + 2] = bias.z + __uint_as_float(r.z);
-      init[4 * g4 + 3] = bias.w + __uint_as_float(r.w);
+      v[4 * g4 + 0] = bias_raw[g4].x + __uint_as_float(res_raw[g4].x);
+      v[4 * g4 + 1] = bias_raw[g4].y + __uint_as_float(res_raw[g4].y);
+      v[4 * g4 + 2] = bias_raw[g4].z + __uint_as_float(res_raw[g4].z);
+      v[4 * g4 + 3] = bias_raw[g4].w + __uint_as_float(res_raw[g4].w);
     }
+    return v;
   };
+  // tile-queue ticket: a straight-line buffer atomic (only thread 0 has an in-range offset; the others are
+  // dropped by the range check) so that its result is awaited where it is used, not where it is issued
+  const __amdgpu_buffer_rsrc_t q_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.tile_counter, 0, 4, 0x00020000);
+  const unsigned q_off = tid == 0 ? 0u : OOBP;
 
   const int grid = gridDim.x;
   int tile = blockIdx.x;
-  issue_patch(tile, 0);
-  init_load(tile);
-  if (tid == 0) slot_write(2, grid + (int)atomicAdd(p.tile_counter, 1u));
+  int c_row0, c_y0, c_x0;            // origin of the tile being computed
+  tile_origin(tile, c_row0, c_y0, c_x0);
+#pragma unroll
+  for (int j = 0; j < MAXP; ++j) issue_piece(j, c_row0, c_y0, c_x0, 0);
+  init_load(c_row0, c_y0, c_x0);
+  {
+    const int t0 = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, q_rsrc, q_off, 0, 0);
+    if (tid == 0) slot_write(2, grid + t0);
+  }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
   int next = slot_read(2);
   int cur = 0;
 
-  f32x16 ready = init;      // bias + residual of the tile about to be computed, already waited for
+#ifdef UT_STAMPS
+  int tiles_done = 0;
+#define UTP_STAMP(IDX)                                                                               \
+  if (tid == 0 && blockIdx.x < 4096 && tiles_done == 1) {                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+    p.stamps[blockIdx.x * 8 + (IDX)] = (long long)__builtin_amdgcn_s_memtime();                      \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+  }
+#else
+#define UTP_STAMP(IDX)
+#endif
+  f32x16 ready = init_combine();      // bias + residual of the tile about to be computed
   for (;;) {
+    UTP_STAMP(0);
     const bool has_next = next < n_tiles;
     f32x16 acc = ready;
-    // the tile after next; two slots alternate so that a wave still reading one is never overrun (the
-    // end-of-tile barrier separates a slot's read from its next write)
-    // (the returning atomic is ISSUED here and consumed after the MFMA stream: waiting for it here would
-    // hold wave 0 - and with it the end-of-tile barrier - for a full memory round trip per tile)
-    unsigned ticket = 0;
-    if (tid == 0) ticket = atomicAdd(p.tile_counter, 1u);
-    if (has_next) {
-      issue_patch(next, cur ^ 1);     // streams in under this tile's MFMAs
-      init_load(next);
-    }
+    // ticket for the tile after next: issued now, consumed before the last tap
+    const int ticket = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, q_rsrc, q_off, 0, 0);
+    int n_row0 = 0, n_y0 = 0, n_x0 = 0;
+    if (has_next) tile_origin(next, n_row0, n_y0, n_x0);
+    UTP_STAMP(1);
 
     const float* patch = patch0 + cur * P_FLOATS;
-    // 9 taps x 4 k-groups, fragments double buffered in registers
+    // 9 taps x 4 k-groups, fragments double buffered in registers.  The requests for the NEXT tile (patch
+    // pieces, residual) are slipped in between MFMA groups of taps 0..6 so that their address arithmetic and
+    // issue run in the shadow of MFMAs already queued.
     float4 wfX, pfX, wfY, pfY;
 #define UTP_READ(SET, TAP, Q)                                                                        \
   {                                                                                                  \
@@ -197,32 +227,36 @@ __global__ __launch_bounds__(512) void conv3x3_c32_patch_kernel(ConvLaunch p, in
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf##SET.z, pf##SET.z, acc, 0, 0, 0);                  \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf##SET.w, pf##SET.w, acc, 0, 0, 0);                  \
   }
+#define UTP_PIN() __builtin_amdgcn_sched_barrier(0)
     UTP_READ(X, 0, 0);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      UTP_READ(Y, tap, 1); __builtin_amdgcn_sched_barrier(0); UTP_MFMA(X); __builtin_amdgcn_sched_barrier(0);
-      UTP_READ(X, tap, 2); __builtin_amdgcn_sched_barrier(0); UTP_MFMA(Y); __builtin_amdgcn_sched_barrier(0);
-      UTP_READ(Y, tap, 3); __builtin_amdgcn_sched_barrier(0); UTP_MFMA(X); __builtin_amdgcn_sched_barrier(0);
-      if (tap < 8) { UTP_READ(X, tap + 1, 0); }
-      __builtin_amdgcn_sched_barrier(0); UTP_MFMA(Y); __builtin_amdgcn_sched_barrier(0);
+      UTP_READ(Y, tap, 1); UTP_PIN(); UTP_MFMA(X); UTP_PIN();
+      if (has_next && tap < MAXP) issue_piece(tap, n_row0, n_y0, n_x0, cur ^ 1);
+      if (has_next && tap == MAXP) init_load(n_row0, n_y0, n_x0);
+      UTP_READ(X, tap, 2); UTP_PIN(); UTP_MFMA(Y); UTP_PIN();
+      UTP_READ(Y, tap, 3); UTP_PIN(); UTP_MFMA(X); UTP_PIN();
+      if (tap < 8) {
+        UTP_READ(X, tap + 1, 0);
+      } else {
+        // everything requested for the next tile was issued at least two taps ago: drain the counter, publish
+        // the ticket and combine bias+residual NOW, in front of the last MFMA group and of the stores (vmcnt
+        // counts stores too: waiting at the barrier would cost every wave a write round trip per tile)
+        UTP_STAMP(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) slot_write(cur, grid + ticket);
+        if (has_next) ready = init_combine();
+        asm volatile("" : "+v"(ready));
+      }
+      UTP_PIN(); UTP_MFMA(Y); UTP_PIN();
     }
 #undef UTP_READ
 #undef UTP_MFMA
-
-    // The next patch (my pieces) and the next tile's residual were requested a whole tile ago: drain the
-    // counter BEFORE the stores below - vmcnt counts stores too, and waiting for them at the barrier would
-    // stall every wave for a full write round trip per tile.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid == 0) slot_write(cur, grid + (int)ticket);
-    // take the next tile's bias+residual out of the load registers HERE, so that the compiler's own wait for
-    // those loads also sits in front of the stores (an opaque use pins the copy to this point)
-    ready = init;
-    asm volatile("" : "+v"(ready));
+#undef UTP_PIN
+    UTP_STAMP(3);
     // epilogue: (ReLU) + 4 x 16-byte stores per lane
     {
-      int img, y0, x0;
-      tile_origin(tile, img, y0, x0);
-      const int m = (img * H + y0 + ly) * W + x0 + lx;
+      const int m = (c_row0 + c_y0 + ly) * W + c_x0 + lx;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int n = 8 * g4 + 4 * fh;
@@ -233,13 +267,19 @@ __global__ __launch_bounds__(512) void conv3x3_c32_patch_kernel(ConvLaunch p, in
         __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, (unsigned)(m * C + n) * 4u, 0, 0);
       }
     }
+    UTP_STAMP(4);
     if (!has_next) break;
     // every wave's pieces of the next patch have landed and everyone is done reading the current one
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
     __builtin_amdgcn_s_barrier();
+    UTP_STAMP(5);
     const int next2 = slot_read(cur);
+#ifdef UT_STAMPS
+    ++tiles_done;
+#endif
     tile = next;
     next = next2;
+    c_row0 = n_row0; c_y0 = n_y0; c_x0 = n_x0;
     cur ^= 1;
   }
 }
