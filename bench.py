@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--frames-per-gpu", type=int, default=1024)
     ap.add_argument("--mode", choices=["known", "unknown"], default="known")
     ap.add_argument("--chunk", type=int, default=0, help="crops per backbone pass (0 = library default)")
-    ap.add_argument("--cpu-frames", type=int, default=96, help="label frames timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=768, help="label frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
@@ -125,7 +125,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
         if os.path.exists(tpath) and f_local == 1024 and known:
             traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
-        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (all instantiations)",
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (all instantiations) + conv3x3_c32_patch_kernel (layer1)",
                     "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "launches_per_step": launches // n_prof, "avg_launch_ms": round(ms / max(launches, 1), 5),

@@ -42,11 +42,13 @@ head = [("fus0 144->108", 144 * 108), ("fus1 108->72", 108 * 72), ("fus2 72->72"
         ("reg1.conv1 76", 9 * 76 * 76), ("reg1.conv2 76", 9 * 76 * 76)]
 seq += [(nm, 2 * mac * 36 * s) for nm, mac in head]
 
-convs = [r for r in rows if "conv_igemm" in r["Kernel_Name"]]
+is_conv = lambda r: "conv_igemm" in r["Kernel_Name"] or "conv3x3_c32_patch" in r["Kernel_Name"]
+convs = [r for r in rows if is_conv(r)]
 last = convs[-len(seq):]
 agg = collections.OrderedDict()
 for (nm, fl), r in zip(seq, last):
-    a = agg.setdefault(nm, [0, 0.0, 0.0, r["Kernel_Name"].split("<")[1].split(">")[0]])
+    tile = r["Kernel_Name"].split("<")[1].split(">")[0] if "<" in r["Kernel_Name"] else "halo patch 16x16"
+    a = agg.setdefault(nm, [0, 0.0, 0.0, tile])
     a[0] += 1; a[1] += dur(r); a[2] += fl
 tot_t = sum(a[1] for a in agg.values()); tot_f = sum(a[2] for a in agg.values())
 print(f"{'conv':28s} {'tile':16s} {'n':>3s} {'total us':>10s} {'TFLOP/s':>8s} {'% of conv time':>8s}")
@@ -56,6 +58,6 @@ print(f"conv total {tot_t/1e3:.3f} ms, {tot_f/tot_t/1e6:.1f} TFLOP/s")
 t0 = int(last[0]["Start_Timestamp"])
 others = collections.Counter()
 for r in rows:
-    if int(r["Start_Timestamp"]) >= t0 - 2e6 and "conv_igemm" not in r["Kernel_Name"]:
+    if int(r["Start_Timestamp"]) >= t0 - 2e6 and not is_conv(r):
         others[r["Kernel_Name"].split("(")[0][-48:]] += dur(r)
 print("other kernels in/around the last step (us):", {k: round(v, 1) for k, v in others.most_common(10)})

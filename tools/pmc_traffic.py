@@ -12,7 +12,7 @@ import sys
 def per_launch(path, counter):
     tot, n = 0.0, 0
     for r in csv.DictReader(open(path)):
-        if "conv_igemm" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+        if ("conv_igemm" in r["Kernel_Name"] or "conv3x3_c32_patch" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
             tot += float(r["Counter_Value"])
             n += 1
     return tot, n
@@ -21,7 +21,7 @@ def per_launch(path, counter):
 fetch, nf = per_launch(sys.argv[1], "FETCH_SIZE")
 write, nw = per_launch(sys.argv[2], "WRITE_SIZE")
 out = {
-    "kernel": "conv_igemm_kernel (all instantiations)", "label": sys.argv[4] if len(sys.argv) > 4 else "",
+    "kernel": "conv_igemm_kernel (all instantiations) + conv3x3_c32_patch_kernel", "label": sys.argv[4] if len(sys.argv) > 4 else "",
     "launches_fetch_pass": nf, "launches_write_pass": nw,
     "FETCH_SIZE_KiB_per_launch_raw": fetch / max(nf, 1), "WRITE_SIZE_KiB_per_launch": write / max(nw, 1),
     "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE counts 64 B per 128-B request)",
