@@ -6,7 +6,7 @@ streams only; tensors cross the boundary as raw device pointers.
 """
 import ctypes
 import os
-from typing import Optional, Tuple
+from typing import Dict, Optional, Tuple
 
 import numpy as np
 import torch
@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libumetrack_hip.so")
 EXPORTS = (
     "ut_weight_blob_floats", "ut_create", "ut_destroy", "ut_last_error", "ut_reserve",
     "ut_set_backbone_chunk", "ut_warp_crops", "ut_backbone", "ut_fuse_temporal_regress",
-    "ut_reset_memory", "ut_get_memory", "ut_fk", "ut_profile_begin", "ut_profile_end",
+    "ut_reset_memory", "ut_get_memory", "ut_fk", "ut_gen_crop_cameras", "ut_profile_begin", "ut_profile_end",
 )
 
 UT_MODE_KNOWN, UT_MODE_UNKNOWN = 0, 1
@@ -68,6 +68,9 @@ def load_library() -> ctypes.CDLL:
     lib.ut_get_memory.argtypes = [vp, f32p, f32p, i32, vp]
     lib.ut_fk.restype = i32
     lib.ut_fk.argtypes = [vp, f32p, i32, f32p, i32, f32p, i32, vp, ctypes.c_float, i32, f32p, vp]
+    lib.ut_gen_crop_cameras.restype = i32
+    lib.ut_gen_crop_cameras.argtypes = [vp, vp, vp, f32p, f32p, i32, f32p, f32p, vp, vp, i32, i32, i32, i32, i32, i32,
+                                        i32, ctypes.c_double, vp, f32p, f32p, vp, vp, vp, vp]
     lib.ut_profile_begin.restype = i32
     lib.ut_profile_begin.argtypes = [vp, vp]
     lib.ut_profile_end.restype = i32
@@ -149,6 +152,53 @@ def fk_stateless(hand_model: torch.Tensor, joint_angles: torch.Tensor, wrist_xf:
                        _ptr(mirror), ctypes.c_float(t_scale), n, _ptr(out), _stream(d))
     if rc != 0:
         raise RuntimeError(f"ut_fk failed ({rc}): {lib.ut_last_error(None).decode()}")
+    return out
+
+
+def gen_crop_cameras(cam_params: torch.Tensor, camera_angles: torch.Tensor, hand_model: torch.Tensor,
+                     joint_limits: torch.Tensor, joint_angles: torch.Tensor, wrist_xf: torch.Tensor,
+                     frame_idx: torch.Tensor, hand_idx: torch.Tensor, n_cams: int, src_wh: Tuple[int, int],
+                     max_views: int = 2, min_vis: int = 19, crop_size: int = arch.CROP,
+                     focal_multiplier: float = 0.8) -> Dict[str, torch.Tensor]:
+    """ut_gen_crop_cameras: crop cameras of n (frame, hand) label poses in one launch, padded to max_views.
+    Returns crop_params [n,V,24] f64, intrinsics [n,V,3,3], extrinsics [n,V,4,4], cam_index [n,V] i32,
+    n_views [n] i32, status [n] i32.  All tensors on one HIP device; no CPU fallback."""
+    lib = load_library()
+    d = joint_angles.device
+    if d.type != "cuda":
+        raise NativeLibraryError("gen_crop_cameras needs tensors on a HIP device (no CPU fallback)")
+    cam_params = _need(cam_params, torch.float64, d, "cam_params").reshape(-1, 32)
+    camera_angles = _need(camera_angles, torch.float64, d, "camera_angles").reshape(-1)
+    hand_model = _need(hand_model, torch.float32, d, "hand_model").reshape(-1, 321)
+    joint_limits = _need(joint_limits, torch.float32, d, "joint_limits").reshape(-1, 44)
+    joint_angles = _need(joint_angles, torch.float32, d, "joint_angles").reshape(-1, 22)
+    wrist_xf = _need(wrist_xf, torch.float32, d, "wrist_xf").reshape(-1, 16)
+    frame_idx = _need(frame_idx, torch.int32, d, "frame_idx").reshape(-1)
+    hand_idx = _need(hand_idx, torch.int64, d, "hand_idx").reshape(-1)
+    n = joint_angles.shape[0]
+    if not (wrist_xf.shape[0] == frame_idx.shape[0] == hand_idx.shape[0] == n):
+        raise ValueError("gen_crop_cameras: joint_angles, wrist_xf, frame_idx and hand_idx disagree on n")
+    if hand_model.shape[0] != joint_limits.shape[0] or hand_model.shape[0] not in (1, n):
+        raise ValueError("gen_crop_cameras: hand_model / joint_limits must hold 1 or n models")
+    if camera_angles.shape[0] != n_cams or cam_params.shape[0] % n_cams:
+        raise ValueError("gen_crop_cameras: cam_params rows must be a multiple of n_cams = len(camera_angles)")
+    if n and (int(frame_idx.max()) + 1) * n_cams > cam_params.shape[0]:
+        raise ValueError("gen_crop_cameras: frame_idx points past cam_params")
+    out = {"crop_params": torch.zeros(n, max_views, 24, dtype=torch.float64, device=d),
+           "intrinsics": torch.zeros(n, max_views, 3, 3, dtype=torch.float32, device=d),
+           "extrinsics": torch.zeros(n, max_views, 4, 4, dtype=torch.float32, device=d),
+           "cam_index": torch.empty(n, max_views, dtype=torch.int32, device=d),
+           "n_views": torch.empty(n, dtype=torch.int32, device=d),
+           "status": torch.empty(n, dtype=torch.int32, device=d)}
+    with torch.cuda.device(d):
+        rc = lib.ut_gen_crop_cameras(None, _ptr(cam_params), _ptr(camera_angles), _ptr(hand_model), _ptr(joint_limits),
+                                     hand_model.shape[0], _ptr(joint_angles), _ptr(wrist_xf), _ptr(frame_idx),
+                                     _ptr(hand_idx), n, n_cams, max_views, min_vis, int(src_wh[0]), int(src_wh[1]),
+                                     crop_size, ctypes.c_double(focal_multiplier), _ptr(out["crop_params"]),
+                                     _ptr(out["intrinsics"]), _ptr(out["extrinsics"]), _ptr(out["cam_index"]),
+                                     _ptr(out["n_views"]), _ptr(out["status"]), _stream(d))
+    if rc != 0:
+        raise RuntimeError(f"ut_gen_crop_cameras failed ({rc}): {lib.ut_last_error(None).decode()}")
     return out
 
 

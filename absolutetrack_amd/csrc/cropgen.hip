@@ -1,0 +1,189 @@
+// Batched crop-camera generation: for every (frame, hand) candidate, in ONE launch,
+// what HandTracker.gen_crop_cameras does per frame on the host in the reference:
+//   crop points = FK of (label pose, neutral pose, open pose)          lib/tracker/perspective_crop.py:89-133
+//   visible-landmark count per fisheye camera                          lib/tracker/perspective_crop.py:54-86
+//   first `max_views` eligible cameras in index order                  :157-178 with sort_camera_index=True
+//   per selected camera: look-at rotation towards the crop centre, roll by the camera angle, x-mirror for
+//   right hands, largest focal that keeps all 63 points in a 96x96 image, times hand_ratio_in_crop
+//                                                                      lib/common/crop.py:15-82, lib/common/affine.py:34-76
+// and the network-side camera inputs of lib/tracker/tracker.py:333-337 (K, world->eye with t in metres).
+// FK in fp32 (the reference runs it in torch fp32), geometry in fp64 (numpy).  One thread per candidate: a few
+// kFLOP and ~1.5 KB each - latency bound; the win over the reference is doing all frames in one launch
+// instead of ~10 ms of numpy/scipy/torch calls per frame.
+#include "ut_fk.h"
+#include "ut_kernels.h"
+#include "ut_math.h"
+
+namespace ut {
+
+namespace {
+
+// world -> eye of a camera given as cam_params row (R at [12..20], t at [21..23] of camera_to_world)
+__device__ inline void world_to_eye_d(const double* cam, const double* w, double* e) {
+  const double* r = cam + 12;
+  const double* t = cam + 21;
+  const double dx = w[0] - t[0], dy = w[1] - t[1], dz = w[2] - t[2];
+  e[0] = r[0] * dx + r[3] * dy + r[6] * dz;
+  e[1] = r[1] * dx + r[4] * dy + r[7] * dz;
+  e[2] = r[2] * dx + r[5] * dy + r[8] * dz;
+}
+
+// Fisheye62 eye -> window (lib/common/camera.py:80-85,122-143,308-312)
+__device__ inline void fisheye_project_d(const double* cam, const double* e, double* win) {
+  const double r = sqrt(e[0] * e[0] + e[1] * e[1]);
+  const double sc = atan2(r, e[2]) / fmax(r, 2.938735877055719e-39);
+  const double ux = e[0] * sc, uy = e[1] * sc;
+  const double k1 = cam[4], k2 = cam[5], k3 = cam[6], k4 = cam[7], p1 = cam[8], p2 = cam[9], k5 = cam[10], k6 = cam[11];
+  const double pi2 = 9.869604401089358;
+  const double r2 = fmin(fmax(ux * ux + uy * uy, -pi2), pi2);
+  const double r4 = r2 * r2, r6 = r2 * r4;
+  const double radial = 1 + k1 * r2 + k2 * r4 + k3 * r6 + k4 * (r4 * r4) + k5 * (r4 * r6) + k6 * (r6 * r6);
+  const double x = ux * radial, y = uy * radial;
+  const double x2 = x * x, y2 = y * y, xy = x * y, rr = x2 + y2;
+  win[0] = (x + (2 * p2 * xy + p1 * (rr + 2 * x2))) * cam[0] + cam[2];
+  win[1] = (y + (2 * p1 * xy + p2 * (rr + 2 * y2))) * cam[1] + cam[3];
+}
+
+__device__ inline void mat3_mul(const double* a, const double* b, double* c) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) c[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void cropgen_kernel(CropGenArgs g) {
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= g.n) return;
+  const int frame = g.frame_idx[s];
+  const int hand = (int)g.hand_idx[s];
+  const float* hm = g.hand_model + (size_t)(g.n_models == 1 ? 0 : s) * 321;
+
+  // ---- crop points: FK of the label pose, the neutral pose and the open pose (all with the label wrist)
+  M34 wrist;
+  const float* x = g.wrist_xf + (size_t)s * 16;
+  for (int k = 0; k < 12; ++k) wrist.m[k] = x[k];
+  if (hand == 1) { wrist.m[0] = -wrist.m[0]; wrist.m[4] = -wrist.m[4]; wrist.m[8] = -wrist.m[8]; }
+  float pts[3][63];
+  float ja[22];
+  for (int k = 0; k < 22; ++k) ja[k] = g.joint_angles[(size_t)s * 22 + k];
+  skin_landmarks_dev(hm, ja, wrist, pts[0]);
+  const float* lim = g.joint_limits + (size_t)(g.n_models == 1 ? 0 : s) * 44;
+  for (int k = 0; k < 22; ++k) ja[k] = lim[2 * k] * 0.5f + lim[2 * k + 1] * (1.0f - 0.5f);   // perspective_crop.py:19-24
+  skin_landmarks_dev(hm, ja, wrist, pts[1]);
+  for (int k = 0; k < 22; ++k) ja[k] = 0.f;
+  skin_landmarks_dev(hm, ja, wrist, pts[2]);
+
+  // crop centre = middle of the bounding box of the 63 points, in fp32 like the reference's
+  // (pts.min + pts.max) / 2.0 on float32 landmarks (crop.py:60)
+  float lo[3], hi[3];
+  for (int d = 0; d < 3; ++d) { lo[d] = 3.0e38f; hi[d] = -3.0e38f; }
+  for (int q = 0; q < 3; ++q)
+    for (int l = 0; l < 21; ++l)
+      for (int d = 0; d < 3; ++d) {
+        lo[d] = fminf(lo[d], pts[q][3 * l + d]);
+        hi[d] = fmaxf(hi[d], pts[q][3 * l + d]);
+      }
+  const double center[3] = {(double)((lo[0] + hi[0]) / 2.0f), (double)((lo[1] + hi[1]) / 2.0f),
+                            (double)((lo[2] + hi[2]) / 2.0f)};
+
+  int n_views = 0, status = 0;
+  for (int ci = 0; ci < g.n_cams && n_views < g.max_views; ++ci) {
+    const double* cam = g.cam_params + ((size_t)frame * g.n_cams + ci) * 32;
+    // visibility count of the label-pose landmarks
+    int vis = 0;
+    for (int l = 0; l < 21; ++l) {
+      const double w[3] = {(double)pts[0][3 * l], (double)pts[0][3 * l + 1], (double)pts[0][3 * l + 2]};
+      double e[3], win[2];
+      world_to_eye_d(cam, w, e);
+      fisheye_project_d(cam, e, win);
+      vis += (win[0] >= 0 && win[0] <= g.src_w - 1 && win[1] >= 0 && win[1] <= g.src_h - 1 && e[2] > 0) ? 1 : 0;
+    }
+    if (vis < g.min_vis) continue;
+
+    // ---- look-at (affine.py:47-76): aim +z at the crop centre, keep the position, roll by the camera angle.
+    // Same operation order as the host code: general inverse of camera_to_world, aim in that eye frame,
+    // inverse back, right-multiply the rotation, inverse again.
+    const double* rc = cam + 12;
+    const double* tc = cam + 21;
+    const double c2w0[16] = {rc[0], rc[1], rc[2], tc[0], rc[3], rc[4], rc[5], tc[1], rc[6], rc[7], rc[8], tc[2], 0, 0, 0, 1};
+    double w2e0[16], e2w[16];
+    inv4(c2w0, w2e0);
+    double c_eye[3];
+    for (int i = 0; i < 3; ++i)
+      c_eye[i] = w2e0[4 * i] * center[0] + w2e0[4 * i + 1] * center[1] + w2e0[4 * i + 2] * center[2] + w2e0[4 * i + 3];
+    const double cn = sqrt(c_eye[0] * c_eye[0] + c_eye[1] * c_eye[1] + c_eye[2] * c_eye[2]);
+    double b[3] = {c_eye[0] / cn, c_eye[1] / cn, c_eye[2] / cn};
+    const double bn = fmax(5.43e-20, sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]));
+    b[0] /= bn; b[1] /= bn; b[2] /= bn;
+    // from_two_vectors((0,0,1), b): v = a x b, R = I + K + K^2 (1-a.b)/max(|v|^2, 1e-15)   (affine.py:34-44)
+    const double v[3] = {-b[1], b[0], 0.0};
+    const double sn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const double k[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
+    double k2[9], aim[9];
+    mat3_mul(k, k, k2);
+    const double f = (1 - b[2]) / fmax(sn * sn, 1e-15);
+    for (int i = 0; i < 9; ++i) aim[i] = ((i % 4 == 0) ? 1.0 : 0.0) + k[i] + k2[i] * f;
+    const double ang = g.camera_angles[ci] * (3.141592653589793 / 180.0);
+    const double rz[9] = {cos(ang), -sin(ang), 0, sin(ang), cos(ang), 0, 0, 0, 1};
+    inv4(w2e0, e2w);
+    double r0[9], r1[9], r2[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) r0[3 * i + j] = e2w[4 * i + j];
+    mat3_mul(r0, aim, r1);
+    mat3_mul(r1, rz, r2);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) e2w[4 * i + j] = r2[3 * i + j];
+    double w2e[16];
+    inv4(e2w, w2e);
+    if (hand == 1)                   // mirror x for right hands: diag(-1,1,1,1) @ w2e (crop.py:63-66)
+      for (int j = 0; j < 4; ++j) w2e[j] = -w2e[j];
+    // ---- intrinsics from the bounding points (crop.py:15-28)
+    double max_ndc = 0.0;
+    bool bad = false;
+    for (int q = 0; q < 3; ++q)
+      for (int l = 0; l < 21; ++l) {
+        const double px = (double)pts[q][3 * l], py = (double)pts[q][3 * l + 1], pz = (double)pts[q][3 * l + 2];
+        const double ex = w2e[0] * px + w2e[1] * py + w2e[2] * pz + w2e[3];
+        const double ey = w2e[4] * px + w2e[5] * py + w2e[6] * pz + w2e[7];
+        const double ez = w2e[8] * px + w2e[9] * py + w2e[10] * pz + w2e[11];
+        if (ez < 0.0001) bad = true;
+        max_ndc = fmax(max_ndc, fmax(fabs(ex / ez), fabs(ey / ez)));
+      }
+    const double cxy = ((double)g.crop_size - 1.0) / 2.0;
+    const double fxy = cxy / max_ndc;
+    if (bad || fxy < 5.0) status = 1;          // "Unable to create crop camera" (crop.py:25-26)
+    const double focal = g.focal_multiplier * fxy;
+    double c2w[16];
+    inv4(w2e, c2w);                             // crop camera_to_world (crop.py:81)
+
+    // ---- outputs
+    double* cp = g.crop_params + ((size_t)s * g.max_views + n_views) * 24;
+    cp[0] = focal; cp[1] = focal; cp[2] = cxy; cp[3] = cxy;
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) cp[4 + 3 * i + j] = c2w[4 * i + j];
+      cp[13 + i] = c2w[4 * i + 3];
+    }
+    for (int i = 16; i < 24; ++i) cp[i] = 0.0;
+    float* kk = g.intrinsics + ((size_t)s * g.max_views + n_views) * 9;
+    kk[0] = (float)focal; kk[1] = 0.f; kk[2] = (float)cxy; kk[3] = 0.f; kk[4] = (float)focal; kk[5] = (float)cxy;
+    kk[6] = 0.f; kk[7] = 0.f; kk[8] = 1.f;
+    // extrinsics = inv(crop camera_to_world) with the translation in metres (tracker.py:335-337)
+    double ext[16];
+    inv4(c2w, ext);
+    float* ex = g.extrinsics + ((size_t)s * g.max_views + n_views) * 16;
+    for (int i = 0; i < 16; ++i) ex[i] = (float)((i % 4 == 3 && i < 12) ? ext[i] * 0.001 : ext[i]);
+    g.cam_index[(size_t)s * g.max_views + n_views] = ci;
+    ++n_views;
+  }
+  for (int vdx = n_views; vdx < g.max_views; ++vdx) g.cam_index[(size_t)s * g.max_views + vdx] = -1;
+  g.n_views[s] = n_views;
+  g.status[s] = status;
+}
+
+hipError_t launch_cropgen(const CropGenArgs& g, hipStream_t s) {
+  if (g.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(cropgen_kernel, dim3((g.n + 63) / 64), dim3(64), 0, s, g);
+  return hipGetLastError();
+}
+
+}  // namespace ut

@@ -593,6 +593,28 @@ int ut_fk(ut_handle h, const float* hand_model, int n_models, const float* joint
   return UT_OK;
 }
 
+int ut_gen_crop_cameras(ut_handle h, const double* cam_params, const double* camera_angles, const float* hand_model,
+                        const float* joint_limits, int n_models, const float* joint_angles, const float* wrist_xf,
+                        const int32_t* frame_idx, const int64_t* hand_idx, int n, int n_cams, int max_views, int min_vis,
+                        int src_w, int src_h, int crop_size, double focal_multiplier, double* crop_params,
+                        float* intrinsics, float* extrinsics, int32_t* cam_index, int32_t* n_views, int32_t* status,
+                        void* stream) {
+  if (n == 0) return UT_OK;
+  if (!cam_params || !camera_angles || !hand_model || !joint_limits || !joint_angles || !wrist_xf || !frame_idx ||
+      !hand_idx || !crop_params || !intrinsics || !extrinsics || !cam_index || !n_views || !status || n < 0 ||
+      (n_models != 1 && n_models != n) || n_cams <= 0 || max_views <= 0 || src_w <= 0 || src_h <= 0 || crop_size <= 1)
+    return fail(h, UT_E_INVALID, "ut_gen_crop_cameras: bad argument");
+  ut::CropGenArgs g{};
+  g.cam_params = cam_params; g.camera_angles = camera_angles; g.hand_model = hand_model; g.joint_limits = joint_limits;
+  g.joint_angles = joint_angles; g.wrist_xf = wrist_xf; g.frame_idx = frame_idx; g.hand_idx = hand_idx;
+  g.n = n; g.n_models = n_models; g.n_cams = n_cams; g.max_views = max_views; g.min_vis = min_vis;
+  g.src_w = src_w; g.src_h = src_h; g.crop_size = crop_size; g.focal_multiplier = focal_multiplier;
+  g.crop_params = crop_params; g.intrinsics = intrinsics; g.extrinsics = extrinsics; g.cam_index = cam_index;
+  g.n_views = n_views; g.status = status;
+  HIPCHK(h, ut::launch_cropgen(g, (hipStream_t)stream));
+  return UT_OK;
+}
+
 int ut_profile_begin(ut_handle h, void* stream) {
   if (!h) return UT_E_INVALID;
   (void)stream;

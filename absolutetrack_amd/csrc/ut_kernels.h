@@ -91,6 +91,27 @@ hipError_t launch_fk(const float* hand_model, int n_models, const float* ja, int
                      const float* xf, int xf_stride, const int64_t* mirror, float t_scale, int n,
                      float* out, hipStream_t s);
 
+// Batched crop-camera generation (cropgen.hip): one candidate = one (frame, hand) label pose.
+struct CropGenArgs {
+  const double* cam_params;     // [n_frames*n_cams,32] source camera rows (layout of ut_warp_crops)
+  const double* camera_angles;  // [n_cams] degrees
+  const float* hand_model;      // [n_models,321]
+  const float* joint_limits;    // [n_models,22,2]
+  const float* joint_angles;    // [n,22]
+  const float* wrist_xf;        // [n,4,4] (mm)
+  const int32_t* frame_idx;     // [n]
+  const int64_t* hand_idx;      // [n]
+  int n, n_models, n_cams, max_views, min_vis, src_w, src_h, crop_size;
+  double focal_multiplier;
+  double* crop_params;          // [n,max_views,24]
+  float* intrinsics;            // [n,max_views,3,3]
+  float* extrinsics;            // [n,max_views,4,4]
+  int32_t* cam_index;           // [n,max_views]  (-1 = unused slot)
+  int32_t* n_views;             // [n]
+  int32_t* status;              // [n] 0 ok, 1 = "Unable to create crop camera"
+};
+hipError_t launch_cropgen(const CropGenArgs& g, hipStream_t s);
+
 hipError_t launch_mem_export(const float* mem /*[slots,36,18]*/, float* out /*[slots,18,36]*/, int slots, hipStream_t s);
 
 hipError_t launch_warp(const uint8_t* src, int n_src, int src_h, int src_w, const double* cam,

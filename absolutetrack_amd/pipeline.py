@@ -124,6 +124,59 @@ def crop_plan_from_labels(lab: Dict[str, np.ndarray], hand_model: HandModel, fra
             "hand_idx": np.asarray(hand_idx, np.int64)}
 
 
+def label_candidates(lab: Dict[str, np.ndarray], frame_ids: Sequence[int], hands: Sequence[int] = (0, 1)):
+    """Flat (frame, hand) candidates with confidence >= 0.5 and the per-frame camera rows, as numpy arrays:
+    the inputs of ut_gen_crop_cameras for these frames (lib/tracker/tracker.py:236-241 confidence gate)."""
+    n_lab = lab["joint_angles"].shape[0]
+    lf = np.asarray(frame_ids, np.int64) % n_lab
+    n_cams = lab["cameras"].shape[0]
+    intr = lab["cameras"][:, 2:14]                                       # fx fy cx cy k1..k6 (pack order)
+    cam = np.zeros((len(lf), n_cams, 32), np.float64)
+    cam[:, :, 0:12] = intr[None]
+    c2w = lab["camera_to_world_transforms"][lf]
+    cam[:, :, 12:21] = c2w[:, :, :3, :3].reshape(len(lf), n_cams, 9)
+    cam[:, :, 21:24] = c2w[:, :, :3, 3]
+    conf = lab["hand_confidences"][lf][:, list(hands)] >= 0.5
+    fi, hi = np.nonzero(conf)
+    hand = np.asarray(hands, np.int64)[hi]
+    return {"cam_params": cam.reshape(-1, 32), "frame_idx": fi.astype(np.int32), "hand_idx": hand,
+            "joint_angles": lab["joint_angles"][lf[fi], hand].astype(np.float32),
+            "wrist_xf": lab["wrist_transforms"][lf[fi], hand].astype(np.float32),
+            "camera_angles": np.asarray(lab["camera_angles"], np.float64),
+            "src_wh": (int(lab["cameras"][0, 0]), int(lab["cameras"][0, 1])), "n_cams": n_cams}
+
+
+def crop_plan_on_device(lab: Dict[str, np.ndarray], hand_model: HandModel, frame_ids: Sequence[int], device,
+                        hands: Sequence[int] = (0, 1), opts: Optional[HandTrackerOpts] = None) -> Dict[str, torch.Tensor]:
+    """crop_plan_from_labels with the per-(frame, hand) geometry done by ONE ut_gen_crop_cameras launch
+    (SURVEY.md section 8 row f1).  Returns device tensors with the same keys and row order.  Hands without an
+    eligible view are dropped like the host path drops them; a candidate the reference would raise on
+    ("Unable to create crop camera") raises here as well."""
+    opts = opts or HandTrackerOpts()
+    dev = torch.device(device)
+    c = label_candidates(lab, frame_ids, hands)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    blob = torch.from_numpy(_native.hand_model_blob(
+        hand_model.joint_rotation_axes, hand_model.joint_rest_positions, hand_model.landmark_rest_positions,
+        hand_model.landmark_rest_bone_weights, hand_model.landmark_rest_bone_indices)).reshape(1, 321).to(dev)
+    cam_params, hand_idx, frame_idx = t(c["cam_params"]), t(c["hand_idx"]), t(c["frame_idx"])
+    g = _native.gen_crop_cameras(cam_params, t(c["camera_angles"]), blob, hand_model.joint_limits.float().to(dev),
+                                 t(c["joint_angles"]), t(c["wrist_xf"]), frame_idx, hand_idx, c["n_cams"], c["src_wh"],
+                                 max_views=MAX_VIEW_NUM, min_vis=opts.min_required_vis_landmarks, crop_size=arch.CROP,
+                                 focal_multiplier=opts.hand_ratio_in_crop)
+    if bool((g["status"] != 0).any()):
+        raise ValueError("Unable to create crop camera")
+    nv = g["n_views"].long()
+    keep = nv > 0
+    used = g["cam_index"] >= 0                                           # [n,V], view slots are filled front to back
+    ends = torch.cumsum(nv, 0)
+    ranges = torch.stack([ends - nv, ends], 1)[keep]
+    src_index = (frame_idx.long()[:, None] * c["n_cams"] + g["cam_index"].long())[used].int()
+    return {"cam_params": cam_params, "crop_params": g["crop_params"][used], "src_index": src_index,
+            "intrinsics": g["intrinsics"][used], "extrinsics": g["extrinsics"][used], "sample_range": ranges,
+            "hand_idx": hand_idx[keep]}
+
+
 def make_batch(plan: dict, src_u8: torch.Tensor, device, independent_frames: bool = True) -> FrameBatch:
     """independent_frames: every hand-sample owns a temporal slot and starts without memory
     (`memory_idx=arange(S)`, `use_memory=False`, the throughput configuration of SURVEY.md section 8 d)."""

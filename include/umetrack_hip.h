@@ -124,6 +124,30 @@ int ut_fk(ut_handle h, const float* hand_model, int n_models, const float* joint
           int ja_stride, const float* wrist_xf, int xf_stride, const int64_t* mirror, float t_scale,
           int n, float* out, void* stream);
 
+/* HandTracker.gen_crop_cameras for a batch of (frame, hand) label poses in one launch
+ * (lib/tracker/tracker.py:222-260 -> lib/tracker/perspective_crop.py:136-180 -> lib/common/crop.py:31-82,
+ * lib/common/affine.py:34-76) plus the network camera inputs of lib/tracker/tracker.py:333-337.
+ *  cam_params    f64 [n_frames*n_cams,32]  source cameras, rows as for ut_warp_crops
+ *  camera_angles f64 [n_cams]              roll of each camera in degrees
+ *  hand_model    f32 [n_models,321], joint_limits f32 [n_models,22,2]; n_models in {1, n}
+ *  joint_angles  f32 [n,22], wrist_xf f32 [n,4,4] (mm, world), frame_idx i32 [n], hand_idx i64 [n]
+ *  Crop points are the landmarks of the pose, of the neutral pose (mid joint limits) and of the
+ *  zero pose (num_crop_points = 63); cameras with >= min_vis of the pose's 21 landmarks inside the
+ *  src_w x src_h image and in front are eligible, the first max_views of them in index order are
+ *  used (sort_camera_index=True), right hands (hand_idx==1) get the x-mirrored crop.
+ *  Outputs, padded to max_views per candidate:
+ *  crop_params f64 [n,max_views,24] (rows as for ut_warp_crops), intrinsics f32 [n,max_views,3,3],
+ *  extrinsics f32 [n,max_views,4,4] (world->eye, translation in metres), cam_index i32 [n,max_views]
+ *  (-1 = unused), n_views i32 [n], status i32 [n] (1 where the reference raises "Unable to create
+ *  crop camera", lib/common/crop.py:25-26).  Stateless: h may be NULL. */
+int ut_gen_crop_cameras(ut_handle h, const double* cam_params, const double* camera_angles,
+                        const float* hand_model, const float* joint_limits, int n_models,
+                        const float* joint_angles, const float* wrist_xf, const int32_t* frame_idx,
+                        const int64_t* hand_idx, int n, int n_cams, int max_views, int min_vis,
+                        int src_w, int src_h, int crop_size, double focal_multiplier,
+                        double* crop_params, float* intrinsics, float* extrinsics,
+                        int32_t* cam_index, int32_t* n_views, int32_t* status, void* stream);
+
 /* Names of the kernels launched by the calls above and the average duration in ms of the
  * dominant (implicit-GEMM convolution) kernel measured with hipEvents on `stream` between
  * ut_profile_begin and ut_profile_end (bench.py roofline leg). */
