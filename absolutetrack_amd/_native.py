@@ -19,7 +19,8 @@ LIB_PATH = os.path.join(_HERE, "libumetrack_hip.so")
 EXPORTS = (
     "ut_weight_blob_floats", "ut_create", "ut_destroy", "ut_last_error", "ut_reserve",
     "ut_set_backbone_chunk", "ut_warp_crops", "ut_backbone", "ut_fuse_temporal_regress",
-    "ut_reset_memory", "ut_get_memory", "ut_fk", "ut_gen_crop_cameras", "ut_profile_begin", "ut_profile_end",
+    "ut_reset_memory", "ut_get_memory", "ut_fk", "ut_gen_crop_cameras", "ut_gen_crop_matrices",
+    "ut_resample_homography", "ut_profile_begin", "ut_profile_end",
 )
 
 UT_MODE_KNOWN, UT_MODE_UNKNOWN = 0, 1
@@ -71,6 +72,11 @@ def load_library() -> ctypes.CDLL:
     lib.ut_gen_crop_cameras.restype = i32
     lib.ut_gen_crop_cameras.argtypes = [vp, vp, vp, f32p, f32p, i32, f32p, f32p, vp, vp, i32, i32, i32, i32, i32, i32,
                                         i32, ctypes.c_double, vp, f32p, f32p, vp, vp, vp, vp]
+    lib.ut_gen_crop_matrices.restype = i32
+    lib.ut_gen_crop_matrices.argtypes = [vp, f32p, f32p, f32p, vp, i32, i32, i32, i32, ctypes.c_double, f32p, f32p, f32p,
+                                         vp, vp]
+    lib.ut_resample_homography.restype = i32
+    lib.ut_resample_homography.argtypes = [vp, vp, i32, i32, i32, i32, f32p, i32, i32, f32p, vp]
     lib.ut_profile_begin.restype = i32
     lib.ut_profile_begin.argtypes = [vp, vp]
     lib.ut_profile_end.restype = i32
@@ -199,6 +205,65 @@ def gen_crop_cameras(cam_params: torch.Tensor, camera_angles: torch.Tensor, hand
                                      _ptr(out["n_views"]), _ptr(out["status"]), _stream(d))
     if rc != 0:
         raise RuntimeError(f"ut_gen_crop_cameras failed ({rc}): {lib.ut_last_error(None).decode()}")
+    return out
+
+
+def gen_crop_matrices(orig_extrinsics: torch.Tensor, orig_intrinsics: torch.Tensor, crop_points: torch.Tensor,
+                      hand_idx: torch.Tensor, crop_size: int = arch.CROP, focal_multiplier: float = 0.95
+                      ) -> Dict[str, torch.Tensor]:
+    """ut_gen_crop_matrices.  orig_extrinsics [F,V,4,4], orig_intrinsics [F,V,3,3], crop_points [F,P,3], hand_idx [F]
+    -> extrinsics_xf [F,V,4,4], new_intrinsics [F,V,3,3], resample_xf [F,V,4,4], status [F,V] (i32)."""
+    lib = load_library()
+    d = orig_extrinsics.device
+    if d.type != "cuda":
+        raise NativeLibraryError("gen_crop_matrices needs tensors on a HIP device (no CPU fallback)")
+    if orig_extrinsics.dim() != 4 or tuple(orig_extrinsics.shape[2:]) != (4, 4):
+        raise ValueError("orig_extrinsics must be [frames, views, 4, 4]")
+    f, v = orig_extrinsics.shape[:2]
+    if tuple(orig_intrinsics.shape) != (f, v, 3, 3):
+        raise ValueError("orig_intrinsics must be [frames, views, 3, 3]")
+    if crop_points.dim() != 3 or crop_points.shape[0] != f or crop_points.shape[2] != 3 or crop_points.shape[1] < 1:
+        raise ValueError("crop_points must be [frames, points, 3]")
+    ext = _need(orig_extrinsics, torch.float32, d, "orig_extrinsics")
+    intr = _need(orig_intrinsics, torch.float32, d, "orig_intrinsics")
+    pts = _need(crop_points, torch.float32, d, "crop_points")
+    hand = _need(hand_idx, torch.int64, d, "hand_idx").reshape(-1)
+    if hand.shape[0] != f:
+        raise ValueError("hand_idx must be [frames]")
+    out = {"extrinsics_xf": torch.empty(f, v, 4, 4, device=d), "new_intrinsics": torch.empty(f, v, 3, 3, device=d),
+           "resample_xf": torch.empty(f, v, 4, 4, device=d), "status": torch.empty(f, v, dtype=torch.int32, device=d)}
+    with torch.cuda.device(d):
+        rc = lib.ut_gen_crop_matrices(None, _ptr(ext), _ptr(intr), _ptr(pts), _ptr(hand), f, v, pts.shape[1], crop_size,
+                                      ctypes.c_double(focal_multiplier), _ptr(out["extrinsics_xf"]),
+                                      _ptr(out["new_intrinsics"]), _ptr(out["resample_xf"]), _ptr(out["status"]), _stream(d))
+    if rc != 0:
+        raise RuntimeError(f"ut_gen_crop_matrices failed ({rc}): {lib.ut_last_error(None).decode()}")
+    return out
+
+
+def resample_homography(src: torch.Tensor, resample_xf: torch.Tensor, out_hw: Tuple[int, int] = (arch.CROP, arch.CROP),
+                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ut_resample_homography.  src [n,H,W] u8 or f32, resample_xf [n,4,4] f32 -> [n,h,w] f32 in [0,1]."""
+    lib = load_library()
+    d = src.device
+    if d.type != "cuda":
+        raise NativeLibraryError("resample_homography needs tensors on a HIP device (no CPU fallback)")
+    if src.dim() != 3 or src.dtype not in (torch.uint8, torch.float32):
+        raise ValueError("src must be [n,H,W] uint8 or float32")
+    n = src.shape[0]
+    xf = _need(resample_xf, torch.float32, d, "resample_xf").reshape(-1, 16)
+    if xf.shape[0] != n:
+        raise ValueError("resample_xf must hold one 4x4 matrix per source image")
+    src = src.contiguous()
+    if out is None:
+        out = torch.empty(n, out_hw[0], out_hw[1], device=d)
+    elif tuple(out.shape) != (n, out_hw[0], out_hw[1]) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != d:
+        raise ValueError("out must be a contiguous float32 [n,h,w] tensor on the source's device")
+    with torch.cuda.device(d):
+        rc = lib.ut_resample_homography(None, _ptr(src), int(src.dtype == torch.float32), n, src.shape[1], src.shape[2],
+                                        _ptr(xf), out_hw[0], out_hw[1], _ptr(out), _stream(d))
+    if rc != 0:
+        raise RuntimeError(f"ut_resample_homography failed ({rc}): {lib.ut_last_error(None).decode()}")
     return out
 
 

@@ -49,6 +49,80 @@ __device__ inline void mat3_mul(const double* a, const double* b, double* c) {
     for (int j = 0; j < 3; ++j) c[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
 }
 
+// Result of aiming a square pinhole crop camera at a point cloud (lib/common/crop.py:31-82).
+struct CropFit {
+  double focal, cxy;
+  double w2e[16];   // new world->eye (after the optional x mirror)
+  double c2w[16];   // its general inverse = the crop camera's camera_to_world_xf
+  bool bad;         // the reference raises "Unable to create crop camera" (crop.py:25-26)
+};
+
+// c2w0: the original camera's camera_to_world (row major 4x4).  Same operation order as the host code
+// (crop.py:57-82, affine.py:47-76): general inverse of camera_to_world, aim +z at `center` in that eye frame,
+// inverse back, right-multiply the rotation by aim and roll, inverse again, mirror, fit the focal length.
+__device__ inline void fit_crop_camera(const double* c2w0, const float* pts, int n_pts, const double* center,
+                                       double angle_deg, bool mirror, int crop_size, double focal_multiplier,
+                                       CropFit& o) {
+  double w2e0[16], e2w[16];
+  inv4(c2w0, w2e0);
+  double c_eye[3];
+  for (int i = 0; i < 3; ++i)
+    c_eye[i] = w2e0[4 * i] * center[0] + w2e0[4 * i + 1] * center[1] + w2e0[4 * i + 2] * center[2] + w2e0[4 * i + 3];
+  const double cn = sqrt(c_eye[0] * c_eye[0] + c_eye[1] * c_eye[1] + c_eye[2] * c_eye[2]);
+  double b[3] = {c_eye[0] / cn, c_eye[1] / cn, c_eye[2] / cn};
+  const double bn = fmax(5.43e-20, sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]));
+  b[0] /= bn; b[1] /= bn; b[2] /= bn;
+  // from_two_vectors((0,0,1), b): v = a x b, R = I + K + K^2 (1-a.b)/max(|v|^2, 1e-15)   (affine.py:34-44)
+  const double v[3] = {-b[1], b[0], 0.0};
+  const double sn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  const double k[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
+  double k2[9], aim[9];
+  mat3_mul(k, k, k2);
+  const double f = (1 - b[2]) / fmax(sn * sn, 1e-15);
+  for (int i = 0; i < 9; ++i) aim[i] = ((i % 4 == 0) ? 1.0 : 0.0) + k[i] + k2[i] * f;
+  const double ang = angle_deg * (3.141592653589793 / 180.0);
+  const double rz[9] = {cos(ang), -sin(ang), 0, sin(ang), cos(ang), 0, 0, 0, 1};
+  inv4(w2e0, e2w);
+  double r0[9], r1[9], r2[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r0[3 * i + j] = e2w[4 * i + j];
+  mat3_mul(r0, aim, r1);
+  mat3_mul(r1, rz, r2);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) e2w[4 * i + j] = r2[3 * i + j];
+  inv4(e2w, o.w2e);
+  if (mirror)                      // diag(-1,1,1,1) @ w2e (crop.py:63-66)
+    for (int j = 0; j < 4; ++j) o.w2e[j] = -o.w2e[j];
+  // intrinsics from the bounding points (crop.py:15-28)
+  double max_ndc = 0.0;
+  bool bad = false;
+  for (int q = 0; q < n_pts; ++q) {
+    const double px = (double)pts[3 * q], py = (double)pts[3 * q + 1], pz = (double)pts[3 * q + 2];
+    const double ex = o.w2e[0] * px + o.w2e[1] * py + o.w2e[2] * pz + o.w2e[3];
+    const double ey = o.w2e[4] * px + o.w2e[5] * py + o.w2e[6] * pz + o.w2e[7];
+    const double ez = o.w2e[8] * px + o.w2e[9] * py + o.w2e[10] * pz + o.w2e[11];
+    if (ez < 0.0001) bad = true;
+    max_ndc = fmax(max_ndc, fmax(fabs(ex / ez), fabs(ey / ez)));
+  }
+  o.cxy = ((double)crop_size - 1.0) / 2.0;
+  const double fxy = o.cxy / max_ndc;
+  o.bad = bad || fxy < 5.0;
+  o.focal = focal_multiplier * fxy;
+  inv4(o.w2e, o.c2w);              // crop.py:81
+}
+
+// middle of the bounding box in fp32 like (pts.min + pts.max) / 2.0 on float32 points (crop.py:60)
+__device__ inline void bbox_center(const float* pts, int n_pts, double* center) {
+  float lo[3], hi[3];
+  for (int d = 0; d < 3; ++d) { lo[d] = 3.0e38f; hi[d] = -3.0e38f; }
+  for (int q = 0; q < n_pts; ++q)
+    for (int d = 0; d < 3; ++d) {
+      lo[d] = fminf(lo[d], pts[3 * q + d]);
+      hi[d] = fmaxf(hi[d], pts[3 * q + d]);
+    }
+  for (int d = 0; d < 3; ++d) center[d] = (double)((lo[d] + hi[d]) / 2.0f);
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(64) void cropgen_kernel(CropGenArgs g) {
@@ -63,28 +137,18 @@ __global__ __launch_bounds__(64) void cropgen_kernel(CropGenArgs g) {
   const float* x = g.wrist_xf + (size_t)s * 16;
   for (int k = 0; k < 12; ++k) wrist.m[k] = x[k];
   if (hand == 1) { wrist.m[0] = -wrist.m[0]; wrist.m[4] = -wrist.m[4]; wrist.m[8] = -wrist.m[8]; }
-  float pts[3][63];
+  float pts[189];
   float ja[22];
   for (int k = 0; k < 22; ++k) ja[k] = g.joint_angles[(size_t)s * 22 + k];
-  skin_landmarks_dev(hm, ja, wrist, pts[0]);
+  skin_landmarks_dev(hm, ja, wrist, pts);
   const float* lim = g.joint_limits + (size_t)(g.n_models == 1 ? 0 : s) * 44;
   for (int k = 0; k < 22; ++k) ja[k] = lim[2 * k] * 0.5f + lim[2 * k + 1] * (1.0f - 0.5f);   // perspective_crop.py:19-24
-  skin_landmarks_dev(hm, ja, wrist, pts[1]);
+  skin_landmarks_dev(hm, ja, wrist, pts + 63);
   for (int k = 0; k < 22; ++k) ja[k] = 0.f;
-  skin_landmarks_dev(hm, ja, wrist, pts[2]);
+  skin_landmarks_dev(hm, ja, wrist, pts + 126);
 
-  // crop centre = middle of the bounding box of the 63 points, in fp32 like the reference's
-  // (pts.min + pts.max) / 2.0 on float32 landmarks (crop.py:60)
-  float lo[3], hi[3];
-  for (int d = 0; d < 3; ++d) { lo[d] = 3.0e38f; hi[d] = -3.0e38f; }
-  for (int q = 0; q < 3; ++q)
-    for (int l = 0; l < 21; ++l)
-      for (int d = 0; d < 3; ++d) {
-        lo[d] = fminf(lo[d], pts[q][3 * l + d]);
-        hi[d] = fmaxf(hi[d], pts[q][3 * l + d]);
-      }
-  const double center[3] = {(double)((lo[0] + hi[0]) / 2.0f), (double)((lo[1] + hi[1]) / 2.0f),
-                            (double)((lo[2] + hi[2]) / 2.0f)};
+  double center[3];
+  bbox_center(pts, 63, center);
 
   int n_views = 0, status = 0;
   for (int ci = 0; ci < g.n_cams && n_views < g.max_views; ++ci) {
@@ -92,7 +156,7 @@ __global__ __launch_bounds__(64) void cropgen_kernel(CropGenArgs g) {
     // visibility count of the label-pose landmarks
     int vis = 0;
     for (int l = 0; l < 21; ++l) {
-      const double w[3] = {(double)pts[0][3 * l], (double)pts[0][3 * l + 1], (double)pts[0][3 * l + 2]};
+      const double w[3] = {(double)pts[3 * l], (double)pts[3 * l + 1], (double)pts[3 * l + 2]};
       double e[3], win[2];
       world_to_eye_d(cam, w, e);
       fisheye_project_d(cam, e, win);
@@ -100,61 +164,14 @@ __global__ __launch_bounds__(64) void cropgen_kernel(CropGenArgs g) {
     }
     if (vis < g.min_vis) continue;
 
-    // ---- look-at (affine.py:47-76): aim +z at the crop centre, keep the position, roll by the camera angle.
-    // Same operation order as the host code: general inverse of camera_to_world, aim in that eye frame,
-    // inverse back, right-multiply the rotation, inverse again.
-    const double* rc = cam + 12;
+    const double* rc = cam + 12;     // camera_to_world rotation (row major), translation at cam+21
     const double* tc = cam + 21;
     const double c2w0[16] = {rc[0], rc[1], rc[2], tc[0], rc[3], rc[4], rc[5], tc[1], rc[6], rc[7], rc[8], tc[2], 0, 0, 0, 1};
-    double w2e0[16], e2w[16];
-    inv4(c2w0, w2e0);
-    double c_eye[3];
-    for (int i = 0; i < 3; ++i)
-      c_eye[i] = w2e0[4 * i] * center[0] + w2e0[4 * i + 1] * center[1] + w2e0[4 * i + 2] * center[2] + w2e0[4 * i + 3];
-    const double cn = sqrt(c_eye[0] * c_eye[0] + c_eye[1] * c_eye[1] + c_eye[2] * c_eye[2]);
-    double b[3] = {c_eye[0] / cn, c_eye[1] / cn, c_eye[2] / cn};
-    const double bn = fmax(5.43e-20, sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]));
-    b[0] /= bn; b[1] /= bn; b[2] /= bn;
-    // from_two_vectors((0,0,1), b): v = a x b, R = I + K + K^2 (1-a.b)/max(|v|^2, 1e-15)   (affine.py:34-44)
-    const double v[3] = {-b[1], b[0], 0.0};
-    const double sn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-    const double k[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
-    double k2[9], aim[9];
-    mat3_mul(k, k, k2);
-    const double f = (1 - b[2]) / fmax(sn * sn, 1e-15);
-    for (int i = 0; i < 9; ++i) aim[i] = ((i % 4 == 0) ? 1.0 : 0.0) + k[i] + k2[i] * f;
-    const double ang = g.camera_angles[ci] * (3.141592653589793 / 180.0);
-    const double rz[9] = {cos(ang), -sin(ang), 0, sin(ang), cos(ang), 0, 0, 0, 1};
-    inv4(w2e0, e2w);
-    double r0[9], r1[9], r2[9];
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) r0[3 * i + j] = e2w[4 * i + j];
-    mat3_mul(r0, aim, r1);
-    mat3_mul(r1, rz, r2);
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) e2w[4 * i + j] = r2[3 * i + j];
-    double w2e[16];
-    inv4(e2w, w2e);
-    if (hand == 1)                   // mirror x for right hands: diag(-1,1,1,1) @ w2e (crop.py:63-66)
-      for (int j = 0; j < 4; ++j) w2e[j] = -w2e[j];
-    // ---- intrinsics from the bounding points (crop.py:15-28)
-    double max_ndc = 0.0;
-    bool bad = false;
-    for (int q = 0; q < 3; ++q)
-      for (int l = 0; l < 21; ++l) {
-        const double px = (double)pts[q][3 * l], py = (double)pts[q][3 * l + 1], pz = (double)pts[q][3 * l + 2];
-        const double ex = w2e[0] * px + w2e[1] * py + w2e[2] * pz + w2e[3];
-        const double ey = w2e[4] * px + w2e[5] * py + w2e[6] * pz + w2e[7];
-        const double ez = w2e[8] * px + w2e[9] * py + w2e[10] * pz + w2e[11];
-        if (ez < 0.0001) bad = true;
-        max_ndc = fmax(max_ndc, fmax(fabs(ex / ez), fabs(ey / ez)));
-      }
-    const double cxy = ((double)g.crop_size - 1.0) / 2.0;
-    const double fxy = cxy / max_ndc;
-    if (bad || fxy < 5.0) status = 1;          // "Unable to create crop camera" (crop.py:25-26)
-    const double focal = g.focal_multiplier * fxy;
-    double c2w[16];
-    inv4(w2e, c2w);                             // crop camera_to_world (crop.py:81)
+    CropFit fit;
+    fit_crop_camera(c2w0, pts, 63, center, g.camera_angles[ci], hand == 1, g.crop_size, g.focal_multiplier, fit);
+    if (fit.bad) status = 1;
+    const double focal = fit.focal, cxy = fit.cxy;
+    const double* c2w = fit.c2w;
 
     // ---- outputs
     double* cp = g.crop_params + ((size_t)s * g.max_views + n_views) * 24;
@@ -178,6 +195,56 @@ __global__ __launch_bounds__(64) void cropgen_kernel(CropGenArgs g) {
   for (int vdx = n_views; vdx < g.max_views; ++vdx) g.cam_index[(size_t)s * g.max_views + vdx] = -1;
   g.n_views[s] = n_views;
   g.status[s] = status;
+}
+
+// torch_data path: _gen_crop_matrices of lib/batched_dataset/data_transform.py:147-212
+// for every (frame, view) of a batch in one launch.  The original cameras are pinholes given as world->eye
+// extrinsics + K; the crop camera is the same look-at fit as above with camera_angle 0; outputs are the network's
+// extrinsics/intrinsics and the pixel homography of data_transform.py:57-76
+//   resample_xf = K_orig44 @ world_to_eye_orig @ eye_to_world_new @ K_new44^-1      (crop pixel -> source pixel).
+// The reference runs this chain in float32 (numpy keeps the dtype of the float32 sample through every
+// np.linalg.inv); here it is float64 and rounded once at the end.
+__global__ __launch_bounds__(64) void cropmat_kernel(CropMatArgs g) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= g.n_frames * g.n_views) return;
+  const int frame = i / g.n_views;
+  const float* pts = g.crop_points + (size_t)frame * g.n_pts * 3;
+  double center[3];
+  bbox_center(pts, g.n_pts, center);
+  double w2e_orig[16], c2w0[16];
+  for (int k = 0; k < 16; ++k) w2e_orig[k] = (double)g.orig_extrinsics[(size_t)i * 16 + k];
+  inv4(w2e_orig, c2w0);            // camera_to_world_xf=np.linalg.inv(world_to_eye_xf)  (data_transform.py:192)
+  CropFit fit;
+  fit_crop_camera(c2w0, pts, g.n_pts, center, 0.0, g.hand_idx[frame] == 1, g.crop_size, g.focal_multiplier, fit);
+  g.status[i] = fit.bad ? 1 : 0;
+  double ext[16];
+  inv4(fit.c2w, ext);              // new_world_to_eye_xf = inv(camera_new.camera_to_world_xf)  (:203)
+  for (int k = 0; k < 16; ++k) g.extrinsics_xf[(size_t)i * 16 + k] = (float)ext[k];
+  float* kn = g.new_intrinsics + (size_t)i * 9;
+  kn[0] = (float)fit.focal; kn[1] = 0.f; kn[2] = (float)fit.cxy; kn[3] = 0.f; kn[4] = (float)fit.focal;
+  kn[5] = (float)fit.cxy; kn[6] = 0.f; kn[7] = 0.f; kn[8] = 1.f;
+  // resample matrix (data_transform.py:57-76)
+  const float* ko = g.orig_intrinsics + (size_t)i * 9;
+  double k_orig[16] = {0}, k_inv[16] = {0}, w2e0[16], t0[16], t1[16], r[16];
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) k_orig[4 * a + b] = (double)ko[3 * a + b];
+  k_orig[15] = 1.0;
+  // only fx, fy, cx, cy of the original K enter the reference's camera_orig (data_transform.py:179-191)
+  k_orig[1] = 0.0; k_orig[4] = 0.0; k_orig[8] = 0.0; k_orig[9] = 0.0; k_orig[10] = 1.0;
+  const double fo = fit.focal, co = fit.cxy;
+  k_inv[0] = 1.0 / fo; k_inv[2] = -co / fo; k_inv[5] = 1.0 / fo; k_inv[6] = -co / fo; k_inv[10] = 1.0; k_inv[15] = 1.0;
+  inv4(c2w0, w2e0);                // world_to_eye_orig = inv(camera_orig.camera_to_world_xf)  (:72)
+  mul4(k_orig, w2e0, t0);
+  mul4(t0, fit.c2w, t1);
+  mul4(t1, k_inv, r);
+  for (int k = 0; k < 16; ++k) g.resample_xf[(size_t)i * 16 + k] = (float)r[k];
+}
+
+hipError_t launch_cropmat(const CropMatArgs& g, hipStream_t s) {
+  const int n = g.n_frames * g.n_views;
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(cropmat_kernel, dim3((n + 63) / 64), dim3(64), 0, s, g);
+  return hipGetLastError();
 }
 
 hipError_t launch_cropgen(const CropGenArgs& g, hipStream_t s) {

@@ -615,6 +615,33 @@ int ut_gen_crop_cameras(ut_handle h, const double* cam_params, const double* cam
   return UT_OK;
 }
 
+int ut_gen_crop_matrices(ut_handle h, const float* orig_extrinsics, const float* orig_intrinsics, const float* crop_points,
+                         const int64_t* hand_idx, int n_frames, int n_views, int n_pts, int crop_size,
+                         double focal_multiplier, float* extrinsics_xf, float* new_intrinsics, float* resample_xf,
+                         int32_t* status, void* stream) {
+  if (n_frames == 0 || n_views == 0) return UT_OK;
+  if (!orig_extrinsics || !orig_intrinsics || !crop_points || !hand_idx || !extrinsics_xf || !new_intrinsics ||
+      !resample_xf || !status || n_frames < 0 || n_views < 0 || n_pts <= 0 || crop_size <= 1)
+    return fail(h, UT_E_INVALID, "ut_gen_crop_matrices: bad argument");
+  ut::CropMatArgs g{};
+  g.orig_extrinsics = orig_extrinsics; g.orig_intrinsics = orig_intrinsics; g.crop_points = crop_points;
+  g.hand_idx = hand_idx; g.n_frames = n_frames; g.n_views = n_views; g.n_pts = n_pts; g.crop_size = crop_size;
+  g.focal_multiplier = focal_multiplier; g.extrinsics_xf = extrinsics_xf; g.new_intrinsics = new_intrinsics;
+  g.resample_xf = resample_xf; g.status = status;
+  HIPCHK(h, ut::launch_cropmat(g, (hipStream_t)stream));
+  return UT_OK;
+}
+
+int ut_resample_homography(ut_handle h, const void* src, int src_is_f32, int n, int src_h, int src_w,
+                           const float* resample_xf, int out_h, int out_w, float* out, void* stream) {
+  if (n == 0) return UT_OK;
+  if (!src || !resample_xf || !out || n < 0 || src_h < 2 || src_w < 2 || out_h <= 0 || out_w <= 0)
+    return fail(h, UT_E_INVALID, "ut_resample_homography: bad argument");
+  HIPCHK(h, ut::launch_resample_homography(src, src_is_f32, n, src_h, src_w, resample_xf, out_h, out_w, out,
+                                           (hipStream_t)stream));
+  return UT_OK;
+}
+
 int ut_profile_begin(ut_handle h, void* stream) {
   if (!h) return UT_E_INVALID;
   (void)stream;

@@ -112,6 +112,23 @@ struct CropGenArgs {
 };
 hipError_t launch_cropgen(const CropGenArgs& g, hipStream_t s);
 
+// torch_data path: crop matrices per (frame, view) and the pinhole->pinhole homography resampler.
+struct CropMatArgs {
+  const float* orig_extrinsics;  // [n_frames*n_views,4,4] world->eye
+  const float* orig_intrinsics;  // [n_frames*n_views,3,3]
+  const float* crop_points;      // [n_frames,n_pts,3]
+  const int64_t* hand_idx;       // [n_frames] (1 = right hand = mirrored crop)
+  int n_frames, n_views, n_pts, crop_size;
+  double focal_multiplier;
+  float* extrinsics_xf;          // [n_frames*n_views,4,4]
+  float* new_intrinsics;         // [n_frames*n_views,3,3]
+  float* resample_xf;            // [n_frames*n_views,4,4]
+  int32_t* status;               // [n_frames*n_views]
+};
+hipError_t launch_cropmat(const CropMatArgs& g, hipStream_t s);
+hipError_t launch_resample_homography(const void* src, int src_is_f32, int n, int src_h, int src_w,
+                                      const float* resample_xf, int out_h, int out_w, float* out, hipStream_t s);
+
 hipError_t launch_mem_export(const float* mem /*[slots,36,18]*/, float* out /*[slots,18,36]*/, int slots, hipStream_t s);
 
 hipError_t launch_warp(const uint8_t* src, int n_src, int src_h, int src_w, const double* cam,

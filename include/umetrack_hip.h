@@ -148,6 +148,28 @@ int ut_gen_crop_cameras(ut_handle h, const double* cam_params, const double* cam
                         double* crop_params, float* intrinsics, float* extrinsics,
                         int32_t* cam_index, int32_t* n_views, int32_t* status, void* stream);
 
+/* torch_data path, lib/batched_dataset/data_transform.py:147-212 (_gen_crop_matrices) for every
+ * (frame, view) of a batch in one launch.
+ *  orig_extrinsics f32 [n_frames*n_views,4,4] world->eye of the (pinhole) source cameras
+ *  orig_intrinsics f32 [n_frames*n_views,3,3] (fx, fy, cx, cy are read)
+ *  crop_points     f32 [n_frames,n_pts,3]     points the crop must enclose (same units as the extrinsics)
+ *  hand_idx        i64 [n_frames]             1 = right hand: x-mirrored crop
+ *  Outputs: extrinsics_xf f32 [.,4,4] (world->eye of the crop camera), new_intrinsics f32 [.,3,3],
+ *  resample_xf f32 [.,4,4] (crop pixel (u,v,1,1) -> source pixel, data_transform.py:57-76),
+ *  status i32 [.] (1 where the reference raises "Unable to create crop camera").  h may be NULL. */
+int ut_gen_crop_matrices(ut_handle h, const float* orig_extrinsics, const float* orig_intrinsics,
+                         const float* crop_points, const int64_t* hand_idx, int n_frames, int n_views,
+                         int n_pts, int crop_size, double focal_multiplier, float* extrinsics_xf,
+                         float* new_intrinsics, float* resample_xf, int32_t* status, void* stream);
+
+/* lib/batched_dataset/data_transform.py:79-144 (_resample_images_batched) + the /255 of :281.
+ *  src: n images [n,src_h,src_w], u8 (src_is_f32 = 0) or f32 (1, the reference's astype(float32) copy)
+ *  resample_xf f32 [n,4,4]; out f32 [n,out_h,out_w] = bilinear sample / 255 where the 2x2
+ *  neighbourhood lies inside the source (0 <= x < src_w-1, 0 <= y < src_h-1), 0 elsewhere.
+ *  h may be NULL. */
+int ut_resample_homography(ut_handle h, const void* src, int src_is_f32, int n, int src_h, int src_w,
+                           const float* resample_xf, int out_h, int out_w, float* out, void* stream);
+
 /* Names of the kernels launched by the calls above and the average duration in ms of the
  * dominant (implicit-GEMM convolution) kernel measured with hipEvents on `stream` between
  * ut_profile_begin and ut_profile_end (bench.py roofline leg). */

@@ -12,6 +12,7 @@ regenerated + expected outputs) under tests/golden/:
   model_known.npz / model_unknown.npz   reference UmeTrackModel outputs (rows a3-a10)
   geometry_rec00.npz                    reference crop cameras + warp coordinate maps (a1,a2)
   fk_user05.npz                         label poses + the reference's STORED gt_keypoints (a12)
+  torch_data.npz                        reference lib.batched_dataset.data_transform crops + matrices (f2)
 and the label data the bench/tests drive the path with:
   absolutetrack_amd/data/recording_00_labels.npz   (from sample_data/recording_00.json)
 
@@ -218,12 +219,36 @@ def export_geometry(labels: dict):
     np.savez_compressed(os.path.join(GOLD, "geometry_rec00.npz"), **out)
 
 
+# ----------------------------------------------------------------------------- torch_data batch path (row f2)
+def export_torch_data():
+    """Reference lib.batched_dataset.data_transform on the seeded sequences of scenarios.torch_data_case."""
+    import lib.batched_dataset.data_transform as rdt
+    assert rdt.__file__.startswith(REF), rdt.__file__
+    out = {}
+    for hand in (0, 1):
+        c = scenarios.torch_data_case(hand)
+        n_frames = c["images"].shape[0]
+        res = np.empty((n_frames, 2, 4, 4), np.float32)
+        for f in range(n_frames):
+            _e, _k, res[f] = rdt._gen_crop_matrices(c["extrinsics"][f], c["intrinsics"][f], c["crop_points"][f], hand == 1,
+                                                    (96, 96))
+        img, ext, intr = rdt._perspective_crop_images(c["images"].astype(np.float32), c["extrinsics"], c["intrinsics"],
+                                                      c["crop_points"], hand, (96, 96))
+        key = f"h{hand}."
+        out[key + "resample_xf"] = res
+        out[key + "images"] = np.asarray(img, np.float32)
+        out[key + "extrinsics_xf"] = ext
+        out[key + "intrinsics"] = intr
+    np.savez_compressed(os.path.join(GOLD, "torch_data.npz"), **out)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     labels = export_labels()
     export_fk()
     export_geometry(labels)
+    export_torch_data()
     np.savez_compressed(os.path.join(GOLD, "model_known.npz"), **run_model_scenario(True))
     np.savez_compressed(os.path.join(GOLD, "model_unknown.npz"), **run_model_scenario(False))
     for f in sorted(os.listdir(GOLD)):

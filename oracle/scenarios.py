@@ -83,3 +83,34 @@ def model_steps(known: bool) -> List[dict]:
         _step("u", 1, [[0, 2], [2, 4], [4, 6], [6, 8]], [3, 0, 1, 2], [False, True, True, False], [1, 0, 1, 0]),
         _step("u", 2, [[0, 2], [2, 4]], [2, 0], [True, True], [0, 0]),
     ]
+
+
+def torch_data_case(hand: int, seed: int = 0, n_frames: int = 4, h: int = 240, w: int = 320) -> Dict[str, np.ndarray]:
+    """Inputs of _perspective_crop_images (lib/batched_dataset/data_transform.py:215-283) for one sequence, in the
+    units the reference holds them after RawSample.scaled(0.001) (metres): two pinhole views per frame placed at the
+    positions of fisheye cameras 1 and 2 of recording_00 and aimed near the hand (seeded offsets, the last frame far
+    enough off that part of the crop leaves the source image), u8 frames, 63 enclosing points from the label pose."""
+    from . import ref_camera
+    lab = labels()
+    hm = hand_model_mm()
+    frames = [5 + 40 * i for i in range(n_frames)]
+    lim = hm["joint_limits"].astype(np.float32)
+    img = synth.synthetic_frames(n_frames, n_cams=2, h=h, w=w, seed=40 + seed + hand)
+    ext = np.zeros((n_frames, 2, 4, 4), np.float32)
+    intr = np.zeros((n_frames, 2, 3, 3), np.float32)
+    pts = np.zeros((n_frames, 63, 3), np.float32)
+    u = synth.counter_uniform(f"torch_data.{hand}", n_frames * 2 * 6, seed).reshape(n_frames, 2, 6)
+    for i, fi in enumerate(frames):
+        ja, wx = lab["joint_angles"][fi, hand], lab["wrist_transforms"][fi, hand]
+        poses = (ja, lim[:, 0] * np.float32(0.5) + lim[:, 1] * np.float32(0.5), np.zeros(22, np.float32))
+        p_mm = np.concatenate([ref_camera.landmarks_from_pose(hm, p, wx, hand) for p in poses], 0)
+        pts[i] = (p_mm * 0.001).astype(np.float32)
+        centre = (pts[i].min(0) + pts[i].max(0)).astype(np.float64) / 2
+        for v, ci in enumerate((1, 2)):
+            c2w = lab["camera_to_world_transforms"][fi, ci].copy()
+            c2w[:3, 3] *= 0.001
+            off = (u[i, v, :3] * 2 - 1) * (0.16 if i == n_frames - 1 else 0.05)
+            ext[i, v] = ref_camera.look_at(np.linalg.inv(c2w), centre + off, 0.0).astype(np.float32)
+            f = w * (0.7 + 0.2 * u[i, v, 3])
+            intr[i, v] = [[f, 0, (w - 1) / 2 + 6 * (u[i, v, 4] - 0.5)], [0, f, (h - 1) / 2 + 6 * (u[i, v, 5] - 0.5)], [0, 0, 1]]
+    return {"images": img, "extrinsics": ext, "intrinsics": intr, "crop_points": pts, "hand": hand}

@@ -214,3 +214,44 @@ def test_synthetic_inputs_are_reproducible():
     assert f.shape == (1, 4, 480, 636) and f.dtype == np.uint8 and f.std() > 20
     st = scenarios.model_steps(True)
     assert [s["sample_range"].tolist() for s in st][0] == [[0, 2], [2, 3], [3, 5]]
+
+
+def test_torch_data_time_step_batching_matches_oracle():
+    """run_inference_torch_data.py:39-85 - host index bookkeeping, no GPU involved."""
+    import torch
+    from absolutetrack_amd import torch_data as td
+    from absolutetrack_amd.hand import HandModel
+    from oracle import ref_torch_data as rt
+    rng = np.random.default_rng(3)
+    bs, seq = 3, 4
+    img = rng.random((bs, seq, 2, 8, 8), dtype=np.float32)
+    k = rng.random((bs, seq, 2, 3, 3), dtype=np.float32)
+    x = rng.random((bs, seq, 2, 4, 4), dtype=np.float32)
+    hand = np.repeat(np.array([[0.0], [1.0], [1.0]], np.float32), seq, 1)
+    axes = rng.random((bs, seq, 22, 3), dtype=np.float32)
+    rest = rng.random((bs, seq, 22, 3), dtype=np.float32)
+    z = torch.zeros(1)
+    hm = HandModel(joint_rotation_axes=torch.from_numpy(axes), joint_rest_positions=torch.from_numpy(rest),
+                   joint_frame_index=z, joint_parent=z, joint_first_child=z, joint_next_sibling=z,
+                   landmark_rest_positions=z, landmark_rest_bone_weights=z, landmark_rest_bone_indices=z, hand_scale=None)
+    pose = td.PoseData(joint_angles=z, wrist_xfs=z, left_hand_model=hm)
+    mi = td.ModelInput(orig_pose_data=pose, s_solved_pose_data=pose, left_images=torch.from_numpy(img),
+                       intrinsics=torch.from_numpy(k), extrinsics_xf=torch.from_numpy(x), hand_idx=torch.from_numpy(hand))
+    for mode in ("multiv", "singlev"):
+        want = rt.unpack_batched_data(img, k, x, hand, axes, rest, mode)
+        got = td.unpack_batched_data(mi, mode)
+        assert len(got) == len(want) == seq
+        for (fd, desc, sk), w in zip(got, want):
+            assert np.array_equal(fd.left_images.numpy(), w["images"])
+            assert np.array_equal(fd.intrinsics.numpy(), w["intrinsics"])
+            assert np.array_equal(fd.extrinsics_xf.numpy(), w["extrinsics"])
+            assert np.array_equal(desc.sample_range.numpy(), w["sample_range"]) and desc.sample_range.dtype == torch.int64
+            assert np.array_equal(desc.memory_idx.numpy(), w["memory_idx"])
+            assert np.array_equal(desc.use_memory.numpy(), w["use_memory"]) and desc.use_memory.dtype == torch.bool
+            assert np.array_equal(desc.hand_idx.numpy(), w["hand_idx"]) and desc.hand_idx.dtype == torch.int64
+            assert np.array_equal(sk.joint_rotation_axes.numpy(), w["axes"])
+            assert np.array_equal(sk.joint_rest_positions.numpy(), w["rest"])
+    with pytest.raises(ValueError):
+        td.unpack_batched_data(mi, "stereo")
+    with pytest.raises(ValueError):
+        rt.unpack_batched_data(img, k, x, hand, axes, rest, "stereo")

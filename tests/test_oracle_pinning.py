@@ -142,3 +142,24 @@ def test_remap_modes_self_consistent():
     mo = np.full((2, 2, 2), -1, np.float32)
     assert ref_camera.remap_bilinear(src, mo, "cv2").max() == 0
     assert ref_camera.cv2_bilinear_tab().sum(-1).min() == 32768 == ref_camera.cv2_bilinear_tab().sum(-1).max()
+
+
+def test_torch_data_oracle_matches_reference_goldens(golden_dir):
+    """Row f2: the restatement of lib/batched_dataset/data_transform.py is bit-identical to the reference's own
+    functions on the seeded sequences (crops, crop extrinsics/intrinsics, resample matrices)."""
+    from oracle import ref_torch_data as rt
+    g = _load(golden_dir, "torch_data.npz")
+    for hand in (0, 1):
+        c = scenarios.torch_data_case(hand)
+        img, ext, intr = rt.perspective_crop_images(c["images"], c["extrinsics"], c["intrinsics"], c["crop_points"], hand,
+                                                    (96, 96))
+        key = f"h{hand}."
+        assert np.array_equal(img, g[key + "images"])
+        assert np.array_equal(ext, g[key + "extrinsics_xf"])
+        assert np.array_equal(intr, g[key + "intrinsics"])
+        res = np.stack([rt.gen_crop_matrices(c["extrinsics"][f], c["intrinsics"][f], c["crop_points"][f], hand == 1,
+                                             (96, 96))[2] for f in range(c["images"].shape[0])])
+        assert np.array_equal(res, g[key + "resample_xf"])
+        # the scenario exercises both fully covered crops and crops that leave the source image
+        cover = (g[key + "images"] > 0).mean(axis=(2, 3))
+        assert cover.max() == 1.0 and cover.min() < 0.95
