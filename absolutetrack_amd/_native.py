@@ -20,7 +20,7 @@ EXPORTS = (
     "ut_weight_blob_floats", "ut_create", "ut_destroy", "ut_last_error", "ut_reserve",
     "ut_set_backbone_chunk", "ut_warp_crops", "ut_backbone", "ut_fuse_temporal_regress",
     "ut_reset_memory", "ut_get_memory", "ut_fk", "ut_gen_crop_cameras", "ut_gen_crop_matrices",
-    "ut_resample_homography", "ut_profile_begin", "ut_profile_end",
+    "ut_resample_homography", "ut_keypoint_metrics", "ut_profile_begin", "ut_profile_end",
 )
 
 UT_MODE_KNOWN, UT_MODE_UNKNOWN = 0, 1
@@ -77,6 +77,8 @@ def load_library() -> ctypes.CDLL:
                                          vp, vp]
     lib.ut_resample_homography.restype = i32
     lib.ut_resample_homography.argtypes = [vp, vp, i32, i32, i32, i32, f32p, i32, i32, f32p, vp]
+    lib.ut_keypoint_metrics.restype = i32
+    lib.ut_keypoint_metrics.argtypes = [vp, f32p, f32p, vp, i32, i32, vp, vp, vp, vp, vp]
     lib.ut_profile_begin.restype = i32
     lib.ut_profile_begin.argtypes = [vp, vp]
     lib.ut_profile_end.restype = i32
@@ -264,6 +266,32 @@ def resample_homography(src: torch.Tensor, resample_xf: torch.Tensor, out_hw: Tu
                                         _ptr(xf), out_hw[0], out_hw[1], _ptr(out), _stream(d))
     if rc != 0:
         raise RuntimeError(f"ut_resample_homography failed ({rc}): {lib.ut_last_error(None).decode()}")
+    return out
+
+
+def keypoint_metrics(gt: torch.Tensor, tracked: torch.Tensor, valid: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """ut_keypoint_metrics.  gt, tracked [hands, frames, 21, 3] f32, valid [hands, frames] bool/u8 on one HIP device ->
+    err f64 [hands, frames], acc / gt_acc f64 [hands, frames-2], valid_acc bool [hands, frames-2]."""
+    lib = load_library()
+    d = gt.device
+    if d.type != "cuda":
+        raise NativeLibraryError("keypoint_metrics needs tensors on a HIP device (no CPU fallback)")
+    if gt.dim() != 4 or tuple(gt.shape[2:]) != (arch.N_LANDMARKS, 3) or gt.shape != tracked.shape:
+        raise ValueError("gt and tracked must both be [hands, frames, 21, 3]")
+    h, t = gt.shape[:2]
+    if tuple(valid.shape) != (h, t):
+        raise ValueError("valid must be [hands, frames]")
+    g, p = _need(gt, torch.float32, d, "gt"), _need(tracked, torch.float32, d, "tracked")
+    v = _need(valid, torch.uint8, d, "valid")
+    ta = max(t - 2, 0)
+    out = {"err": torch.empty(h, t, dtype=torch.float64, device=d), "acc": torch.empty(h, ta, dtype=torch.float64, device=d),
+           "gt_acc": torch.empty(h, ta, dtype=torch.float64, device=d), "valid_acc": torch.zeros(h, ta, dtype=torch.uint8, device=d)}
+    with torch.cuda.device(d):
+        rc = lib.ut_keypoint_metrics(None, _ptr(g), _ptr(p), _ptr(v), h, t, _ptr(out["err"]), _ptr(out["acc"]),
+                                     _ptr(out["gt_acc"]), _ptr(out["valid_acc"]), _stream(d))
+    if rc != 0:
+        raise RuntimeError(f"ut_keypoint_metrics failed ({rc}): {lib.ut_last_error(None).decode()}")
+    out["valid_acc"] = out["valid_acc"].bool()
     return out
 
 

@@ -642,6 +642,17 @@ int ut_resample_homography(ut_handle h, const void* src, int src_is_f32, int n, 
   return UT_OK;
 }
 
+int ut_keypoint_metrics(ut_handle h, const float* gt, const float* tracked, const uint8_t* valid, int n_hands, int n_frames,
+                        double* err, double* acc, double* gt_acc, uint8_t* valid_acc, void* stream) {
+  if (n_hands == 0 || n_frames == 0) return UT_OK;
+  if (!gt || !tracked || !valid || !err || n_hands < 0 || n_frames < 0 ||
+      (n_frames >= 3 && (!acc || !gt_acc || !valid_acc)))
+    return fail(h, UT_E_INVALID, "ut_keypoint_metrics: bad argument");
+  HIPCHK(h, ut::launch_keypoint_metrics(gt, tracked, valid, n_hands, n_frames, err, acc, gt_acc, valid_acc,
+                                        (hipStream_t)stream));
+  return UT_OK;
+}
+
 int ut_profile_begin(ut_handle h, void* stream) {
   if (!h) return UT_E_INVALID;
   (void)stream;

@@ -129,6 +129,9 @@ hipError_t launch_cropmat(const CropMatArgs& g, hipStream_t s);
 hipError_t launch_resample_homography(const void* src, int src_is_f32, int n, int src_h, int src_w,
                                       const float* resample_xf, int out_h, int out_w, float* out, hipStream_t s);
 
+hipError_t launch_keypoint_metrics(const float* gt, const float* tracked, const uint8_t* valid, int n_hands, int n_frames,
+                                   double* err, double* acc, double* gt_acc, uint8_t* valid_acc, hipStream_t s);
+
 hipError_t launch_mem_export(const float* mem /*[slots,36,18]*/, float* out /*[slots,18,36]*/, int slots, hipStream_t s);
 
 hipError_t launch_warp(const uint8_t* src, int n_src, int src_h, int src_w, const double* cam,

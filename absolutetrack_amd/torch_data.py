@@ -191,10 +191,10 @@ def unpack_batched_data(training_input: ModelInput, seq_mode: str
     return steps
 
 
-def eval_batch(model, model_input: ModelInput, model_target: ModelTarget, cur_mode: str, use_skel: bool, device
-               ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Run a collated batch through the model step by step and return (gt_keypoints, output_keypoints)
-    [bs, seq, 21, 3] (run_inference_torch_data.py:88-130)."""
+def eval_batch_keypoints(model, model_input: ModelInput, model_target: ModelTarget, cur_mode: str, use_skel: bool, device
+                         ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Run a collated batch through the model step by step; (gt_keypoints, output_keypoints) [bs, seq, 21, 3] in
+    metres (run_inference_torch_data.py:88-130)."""
     hand_model = mirrored_hand_model(model_input.orig_pose_data.left_hand_model, model_input.hand_idx == 1)
     outputs = []
     for frame_data, frame_desc, skel_input in unpack_batched_data(model_input, cur_mode):
@@ -211,3 +211,10 @@ def eval_batch(model, model_input: ModelInput, model_target: ModelTarget, cur_mo
     gt_keypoints = skin_landmarks(hand_model, target.joint_angles, target.wrist_xfs)
     output_keypoints = skin_landmarks(hand_model, batched.joint_angles, batched.wrist_xfs)
     return gt_keypoints, output_keypoints
+
+
+def _eval_batch(model, model_input: ModelInput, model_target: ModelTarget, cur_mode: str, use_skel: bool, device
+                ) -> torch.Tensor:
+    """Per-sequence mean keypoint error in mm [bs] (run_inference_torch_data.py:88-135)."""
+    gt_keypoints, output_keypoints = eval_batch_keypoints(model, model_input, model_target, cur_mode, use_skel, device)
+    return (gt_keypoints - output_keypoints).norm(dim=-1).mean(dim=(1, 2)) * 1000

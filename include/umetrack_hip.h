@@ -170,6 +170,16 @@ int ut_gen_crop_matrices(ut_handle h, const float* orig_extrinsics, const float*
 int ut_resample_homography(ut_handle h, const void* src, int src_is_f32, int n, int src_h, int src_w,
                            const float* resample_xf, int out_h, int out_w, float* out, void* stream);
 
+/* Per-frame metrics of the eval scripts (load_eval.py:26-45, run_eval_known_skeleton.py:92-93).
+ *  gt, tracked f32 [n_hands,n_frames,21,3]; valid u8 [n_hands,n_frames]
+ *  err f64 [n_hands,n_frames]       mean over landmarks of |gt - tracked| (every frame; mask with `valid`)
+ *  acc, gt_acc f64 [n_hands,n_frames-2]  mean |p[t] + p[t+2] - 2 p[t+1]| of tracked / gt
+ *  valid_acc u8 [n_hands,n_frames-2]     valid[t] & valid[t+1] & valid[t+2]
+ *  (acc outputs may be NULL only if n_frames < 3).  h may be NULL. */
+int ut_keypoint_metrics(ut_handle h, const float* gt, const float* tracked, const uint8_t* valid, int n_hands,
+                        int n_frames, double* err, double* acc, double* gt_acc, uint8_t* valid_acc,
+                        void* stream);
+
 /* Names of the kernels launched by the calls above and the average duration in ms of the
  * dominant (implicit-GEMM convolution) kernel measured with hipEvents on `stream` between
  * ut_profile_begin and ut_profile_end (bench.py roofline leg). */

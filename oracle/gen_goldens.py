@@ -13,6 +13,8 @@ regenerated + expected outputs) under tests/golden/:
   geometry_rec00.npz                    reference crop cameras + warp coordinate maps (a1,a2)
   fk_user05.npz                         label poses + the reference's STORED gt_keypoints (a12)
   torch_data.npz                        reference lib.batched_dataset.data_transform crops + matrices (f2)
+  metrics.npz                           reference load_eval._compute_metrics / metric_utils outputs (f4)
+  *.torch.idx / *.torch.bin             files from the product's writer, verified readable by the reference's TorchIdx (f3)
 and the label data the bench/tests drive the path with:
   absolutetrack_amd/data/recording_00_labels.npz   (from sample_data/recording_00.json)
 
@@ -31,7 +33,7 @@ sys.path.insert(0, REPO)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from absolutetrack_amd import arch, synth  # noqa: E402
+from absolutetrack_amd import arch, formats, synth  # noqa: E402
 from oracle import ref_camera, ref_fk, scenarios, stored_eval  # noqa: E402
 
 # From here on `lib` must be the REFERENCE's package.  The reference's lib/ is a namespace package (no
@@ -242,6 +244,48 @@ def export_torch_data():
     np.savez_compressed(os.path.join(GOLD, "torch_data.npz"), **out)
 
 
+# ----------------------------------------------------------------------------- metrics (row f4)
+def export_metrics():
+    """Reference load_eval._compute_metrics + lib.common.metric_utils on the seeded eval-result arrays."""
+    import lib.common.metric_utils as rmu
+    import load_eval as rle
+    assert rmu.__file__.startswith(REF) and rle.__file__.startswith(REF)
+    c = scenarios.metrics_case()
+    m = rle._compute_metrics(c["gt_keypoints"], c["tracked_keypoints"], c["valid_tracking"])
+    pck = rmu.PCK_curve(m.keypoint_errors, rmu.PCK_THRESHOLDS) * 100.0
+    per_hand = rmu.PCK_curve(np.linalg.norm(c["gt_keypoints"] - c["tracked_keypoints"], axis=-1), rmu.PCK_THRESHOLDS,
+                             mask=np.repeat(c["valid_tracking"][..., None], 21, -1).astype(np.float64), axis=0)
+    np.savez_compressed(os.path.join(GOLD, "metrics.npz"), keypoint_errors=m.keypoint_errors,
+                        keypoint_accelerations=m.keypoint_accelerations,
+                        gt_keypoint_accelerations=m.gt_keypoint_accelerations, pck=pck,
+                        auc=np.float64(rmu.normalized_AUC(rmu.PCK_THRESHOLDS, pck)), pck_per_hand=per_hand,
+                        auc_per_hand=rmu.normalized_AUC(rmu.PCK_THRESHOLDS, per_hand))
+
+
+# ----------------------------------------------------------------------------- .torch.idx/.bin (row f3)
+def export_idxbin():
+    """Fixture files written by the product's writer; the REFERENCE's TorchIdx must parse them to the same data."""
+    import lib.data_utils.idxbinfile as ridx
+    assert ridx.__file__.startswith(REF)
+    c = scenarios.idxbin_case()
+    for name, frames in (("seq_mono", c["mono"]), ("seq_labels", c["labels"]), ("ragged_f32", c["ragged"])):
+        path = os.path.join(GOLD, name + ".torch.idx")
+        formats.write_torch_idx_bin(path, frames)
+        ref = ridx.TorchIdx(path)
+        assert len(ref) == len(frames)
+        with open(ref.bin_path, "rb") as f:
+            raw = f.read()
+        # (the reference's read_bin() of a non-uniform file trips over its own map_dataset(range); go per frame)
+        whole = ref.view_buffer(raw) if ref.shape is not None else None
+        for i in range(len(frames)):
+            got = whole[i] if whole is not None else ref.view_buffer_at(i, raw)
+            if isinstance(frames[i], np.ndarray):
+                assert np.array_equal(got, frames[i]) and got.dtype == frames[i].dtype, (name, i)
+            else:
+                assert got == frames[i], (name, i)
+    assert ridx.TorchIdx(os.path.join(GOLD, "seq_mono.torch.idx")).shape == (3, 2, 2, 16, 24)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
@@ -249,6 +293,8 @@ def main():
     export_fk()
     export_geometry(labels)
     export_torch_data()
+    export_metrics()
+    export_idxbin()
     np.savez_compressed(os.path.join(GOLD, "model_known.npz"), **run_model_scenario(True))
     np.savez_compressed(os.path.join(GOLD, "model_unknown.npz"), **run_model_scenario(False))
     for f in sorted(os.listdir(GOLD)):

@@ -114,3 +114,36 @@ def torch_data_case(hand: int, seed: int = 0, n_frames: int = 4, h: int = 240, w
             f = w * (0.7 + 0.2 * u[i, v, 3])
             intr[i, v] = [[f, 0, (w - 1) / 2 + 6 * (u[i, v, 4] - 0.5)], [0, f, (h - 1) / 2 + 6 * (u[i, v, 5] - 0.5)], [0, 0, 1]]
     return {"images": img, "extrinsics": ext, "intrinsics": intr, "crop_points": pts, "hand": hand}
+
+
+def metrics_case(seed: int = 0, n_frames: int = 60) -> Dict[str, np.ndarray]:
+    """Eval-result-shaped arrays (run_eval_known_skeleton.py:62-64): float32-valued keypoints in float64 arrays
+    [2, T, 21, 3] (mm) - a smooth random walk as ground truth, tracked = gt + noise with a few gross errors so the
+    PCK curve is not saturated - and a validity mask with gaps."""
+    steps = synth.counter_normal("metrics.walk", 2 * n_frames * 63, seed).reshape(2, n_frames, 21, 3)
+    gt = (np.cumsum(np.cumsum(steps * 0.4, axis=1), axis=1) + 300.0).astype(np.float32)
+    noise = synth.counter_normal("metrics.noise", 2 * n_frames * 63, seed).reshape(2, n_frames, 21, 3) * 6.0
+    gross = synth.counter_uniform("metrics.gross", 2 * n_frames, seed).reshape(2, n_frames, 1, 1) > 0.9
+    tracked = (gt + noise + gross * 80.0).astype(np.float32)
+    valid = synth.counter_uniform("metrics.valid", 2 * n_frames, seed).reshape(2, n_frames) > 0.2
+    tracked[~valid] = 0
+    gt_masked = gt.copy()
+    gt_masked[~valid] = 0        # the eval scripts leave untracked frames at zero in both arrays
+    return {"gt_keypoints": gt_masked.astype(np.float64), "tracked_keypoints": tracked.astype(np.float64),
+            "valid_tracking": valid}
+
+
+def idxbin_case(seed: int = 0) -> Dict[str, object]:
+    """Small torch_data-style frames: a uniform uint8 image block per sequence, msgpack label dicts, and a ragged
+    float32 file (lib/data_utils/idxbinfile.py supports frames of differing shape)."""
+    u = synth.counter_uniform("idxbin.mono", 3 * 2 * 2 * 16 * 24, seed)
+    mono = np.floor(u * 256).astype(np.uint8).reshape(3, 2, 2, 16, 24)
+    labels = []
+    for i in range(3):
+        v = synth.counter_uniform(f"idxbin.lab{i}", 40, seed)
+        labels.append({"hand": [float(i % 2)] * 2, "joint_angles": v[:8].reshape(2, 4).tolist(),
+                       "extrinsics": v[8:40].reshape(2, 4, 4).tolist(),
+                       "hand_model": {"joint_rest_positions": v[:6].reshape(2, 3).tolist(), "hand_scale": 1.0}})
+    ragged = [synth.counter_normal(f"idxbin.r{i}", n, seed).astype(np.float32).reshape(shape)
+              for i, (n, shape) in enumerate([(6, (2, 3)), (4, (4,)), (24, (2, 3, 4))])]
+    return {"mono": mono, "labels": labels, "ragged": ragged}

@@ -164,7 +164,9 @@ def test_sequence_batch_through_the_model_matches_oracle(use_skel):
     model = UmeTrackModel(sd)
     model.eval()
     model.to(DEV)
-    gt_kp, out_kp = td.eval_batch(model, model_input, model_target, "multiv", use_skel, DEV)
+    gt_kp, out_kp = td.eval_batch_keypoints(model, model_input, model_target, "multiv", use_skel, DEV)
+    err_mm = td._eval_batch(model, model_input, model_target, "multiv", use_skel, DEV)
+    assert tuple(err_mm.shape) == (2,) and torch.allclose(err_mm, (gt_kp - out_kp).norm(dim=-1).mean(dim=(1, 2)) * 1000, rtol=1e-4)
     assert tuple(out_kp.shape) == (2, 4, 21, 3) and tuple(gt_kp.shape) == (2, 4, 21, 3)
     # oracle: same crops and matrices, reference arithmetic on the CPU
     om = ref_model.OracleModel(sd)
