@@ -22,4 +22,10 @@ Pinning status (see DESIGN.md "Oracle"):
   * bilinear interpolation arithmetic of cv2.remap (a1): PARITY UNPINNED - OpenCV
     is absent and the reference stores no crop; float-bilinear and an OpenCV
     fixed-point emulation are both provided and compared self-consistently only.
+  * section 8(f) rows: f1 crop-camera generation is the geometry pinned above; f2 torch_data path
+    (ref_torch_data.py) pinned, bit-identical to the reference's lib.batched_dataset.data_transform on
+    tests/golden/torch_data.npz (its _unpack_batched_data lives in a script importing pytorch3d-dependent
+    modules and is restated from the text: index bookkeeping only); f4 metrics pinned by
+    tests/golden/metrics.npz (reference load_eval._compute_metrics / lib.common.metric_utils); f3 file
+    fixtures were parsed back by the reference's own TorchIdx when they were generated.
 """
