@@ -209,6 +209,36 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
   }
 #define UT_FETCH(DSTBUF) { UT_FETCH_PART(0, DSTBUF); UT_FETCH_PART(1, DSTBUF); UT_FETCH_PART(2, DSTBUF); }
 
+  // Finer interleave (UT_FINE_FETCH): one 1-KB piece in front of every MFMA quad instead of three bursts.
+  // The per-chunk tap arithmetic is done with piece 0 and kept in f_tap_off / f_dst.
+  int f_tap_off = 0, f_dy = 0, f_dx = 0;
+  unsigned f_dst = 0;
+#define UT_FETCH_PIECE(IDX, DSTBUF)                                                                  \
+  {                                                                                                  \
+    if ((IDX) == 0) {                                                                                \
+      f_dy = 0; f_dx = 0;                                                                            \
+      if (p.ksize == 3) { f_dy = (tap * 11) >> 5; f_dx = tap - 3 * f_dy; }                           \
+      f_tap_off = (f_dy * p.W + f_dx) * p.cin + ch_base + ch;                                        \
+      f_dst = smem_addr + (unsigned)(((DSTBUF) * STAGE + 8 * wave_u * LDS_ROW) * 4);                 \
+    }                                                                                                \
+    if constexpr ((IDX) < AP) {                                                                      \
+      constexpr int i = (IDX);                                                                       \
+      const int iy = a_iy[i] + f_dy, ix = a_ix[i] + f_dx;                                            \
+      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;                  \
+      const unsigned off = ok ? (unsigned)(a_pix[i] + f_tap_off) * 4u : OOB;                         \
+      UT_DIAG_A(dma16(a_words, f_dst + 32 * i * LDS_ROW * 4, off));                                  \
+    } else if constexpr ((IDX) < AP + BP) {                                                          \
+      constexpr int i = (IDX) - AP;                                                                  \
+      UT_DIAG_B(dma16(b_words, f_dst + (BM + 32 * i) * LDS_ROW * 4, b_off + i * b_row_step));        \
+    }                                                                                                \
+    if ((IDX) == AP + BP - 1) { /* advance to the next chunk */                                      \
+      b_off += BK * 4;                                                                               \
+      ch += BK;                                                                                      \
+      if (ch >= p.cslice) { ch -= p.cslice; ++tap; }                                                 \
+      if (tap >= taps) { tap -= taps; ch_base += p.cslice; }                                         \
+    }                                                                                                \
+  }
+
   // MFMA C layout with the operands as above: lane = pixel (column fr of the 32-pixel fragment), register e =
   // output channel (e&3) + 8*(e>>2) + 4*fh of the 32-channel fragment.  Four consecutive registers are four
   // consecutive channels of one pixel: one 16-byte access in NHWC.
@@ -270,19 +300,47 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     _Pragma("unroll") for (int i = 0; i < MI; ++i) af##SET[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDS_ROW); \
     _Pragma("unroll") for (int j = 0; j < NI; ++j) bf##SET[j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_ROW); \
   }
+#define UT_MFMA_STEP(SET, C)                                                                         \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
+      _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                 \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[j].C, af##SET[i].C, acc[i][j], 0, 0, 0);
+  /* weights are the MFMA "A" operand, pixels the "B" operand: D = W x im2col^T, so a lane owns ONE pixel
+     (column) and 4 consecutive output channels per register quad - 16-byte NHWC accesses.  The MI*NI
+     accumulators are visited round-robin: consecutive MFMAs of a wave are independent (a back-to-back
+     dependent 32x32x2 chain issues every ~68 cycles instead of 64 when the wave has the pipe to itself) */
 #define UT_MFMA(SET)                                                                                 \
   {                                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
-      _Pragma("unroll") for (int j = 0; j < NI; ++j) {                                               \
-        /* weights are the MFMA "A" operand, pixels the "B" operand: D = W x im2col^T, so a lane owns ONE     \
-           pixel (column) and 4 consecutive output channels per register quad - 16-byte NHWC accesses */      \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[j].x, af##SET[i].x, acc[i][j], 0, 0, 0); \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[j].y, af##SET[i].y, acc[i][j], 0, 0, 0); \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[j].z, af##SET[i].z, acc[i][j], 0, 0, 0); \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[j].w, af##SET[i].w, acc[i][j], 0, 0, 0); \
-      }                                                                                              \
+    UT_MFMA_STEP(SET, x) UT_MFMA_STEP(SET, y) UT_MFMA_STEP(SET, z) UT_MFMA_STEP(SET, w)              \
   }
 #define UT_PIN() __builtin_amdgcn_sched_barrier(0)
+#define UT_MFMA_Q(SET, Q)                                                                            \
+  {                                                                                                  \
+    constexpr int i = (Q) / NI, j = (Q) % NI;                                                        \
+    if constexpr ((Q) < MI * NI) {                                                                   \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[j].x, af##SET[i].x, acc[i][j], 0, 0, 0); \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[j].y, af##SET[i].y, acc[i][j], 0, 0, 0); \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[j].z, af##SET[i].z, acc[i][j], 0, 0, 0); \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[j].w, af##SET[i].w, acc[i][j], 0, 0, 0); \
+    }                                                                                                \
+  }
+  // group G of a chunk with up to 4 MFMA quads; piece (G*MI*NI + q) goes in front of quad q
+#define UT_GROUP_FINE(SET, G, DSTBUF)                                                                \
+  {                                                                                                  \
+    UT_FETCH_PIECE((G) * MI * NI + 0, DSTBUF); UT_PIN(); UT_MFMA_Q(SET, 0); UT_PIN();                \
+    if constexpr (MI * NI > 1) { UT_FETCH_PIECE((G) * MI * NI + 1, DSTBUF); UT_PIN(); UT_MFMA_Q(SET, 1); UT_PIN(); } \
+    if constexpr (MI * NI > 2) { UT_FETCH_PIECE((G) * MI * NI + 2, DSTBUF); UT_PIN(); UT_MFMA_Q(SET, 2); UT_PIN(); } \
+    if constexpr (MI * NI > 3) { UT_FETCH_PIECE((G) * MI * NI + 3, DSTBUF); UT_PIN(); UT_MFMA_Q(SET, 3); UT_PIN(); } \
+  }
+#define UT_CHUNK_FINE(buf)                                                                           \
+  {                                                                                                  \
+    static_assert(3 * MI * NI >= AP + BP && MI * NI <= 4, "pieces must fit the MFMA quads in front of the barrier"); \
+    UT_READ(Y, buf, 1); UT_PIN(); UT_GROUP_FINE(X, 0, (buf) ^ 1);                                    \
+    UT_READ(X, buf, 2); UT_PIN(); UT_GROUP_FINE(Y, 1, (buf) ^ 1);                                    \
+    UT_READ(Y, buf, 3); UT_PIN(); UT_GROUP_FINE(X, 2, (buf) ^ 1);                                    \
+    UT_MAYBE_STAGE((buf) ^ 1);                                                                       \
+    UT_BARRIER();                                                                                    \
+    UT_READ(X, (buf) ^ 1, 0); UT_PIN(); UT_MFMA(Y); UT_PIN();                                        \
+  }
 
   // One chunk, software pipelined against LDS latency and the barrier.  On entry set X holds the q=0
   // fragments of this chunk (read under the previous chunk's last MFMA group).  The reads of group q+1 are
@@ -325,7 +383,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     const int steps = rank * p.stagger;       // units of 512 cycles
     for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(8);
   }
-  volatile int* next_slot = reinterpret_cast<volatile int*>(smem + 2 * STAGE);   // one int behind the staging area
+  // Tile-queue slot: one int behind the staging area, accessed with explicit DS instructions - a `volatile int*`
+  // into LDS compiles to FLAT accesses, after which every fragment wait in the chunk loop becomes lgkmcnt(0).
+  const unsigned slot_addr = smem_addr + (unsigned)(2 * STAGE * 4);
+#define UT_SLOT_WRITE(V) asm volatile("ds_write_b32 %0, %1" ::"v"(slot_addr), "v"(V) : "memory")
   int tile = slot;
   UT_SETUP(tile);
   UT_FETCH(0);
@@ -347,7 +408,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     // steady state: fetch chunk c+1 (loads stay in flight under the MFMAs), compute chunk c
     for (int c = 0; c + 1 < n_chunks; ++c) {
 #ifndef UT_DIAG_NO_FETCH    /* timing-only ablations for tools/diag (results are wrong with any of them) */
-#ifdef UT_BURST_FETCH
+#if defined(UT_FINE_FETCH)
+      if constexpr (DMA && 3 * MI * NI >= AP + BP && MI * NI == 4) {
+        UT_CHUNK_FINE(buf);
+      } else {
+        UT_CHUNK(buf, UT_FETCH_PART(0, buf ^ 1), UT_FETCH_PART(1, buf ^ 1), UT_FETCH_PART(2, buf ^ 1));
+      }
+#elif defined(UT_BURST_FETCH)
       UT_FETCH(buf ^ 1);
       UT_CHUNK(buf, , , );
 #else
@@ -357,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
       UT_CHUNK(buf, , , );
 #endif
       buf ^= 1;
-      if (c == 0 && tid == 0) *next_slot = grid + ticket;   // ordered before its read by the later chunk barriers
+      if (c == 0 && tid == 0) UT_SLOT_WRITE(grid + ticket);   // ordered before its read by the later chunk barriers
     }
 #ifdef UT_STAMPS
     if (tiles_done == 0) UT_STAMP(2);
@@ -370,10 +437,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     // staging inside UT_CHUNK rewrites stale registers into the idle buffer: harmless)
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     if (n_chunks <= 2) {                  // too few chunk barriers to order the queue slot: do it explicitly
-      if (n_chunks == 1 && tid == 0) *next_slot = grid + ticket;
+      if (n_chunks == 1 && tid == 0) UT_SLOT_WRITE(grid + ticket);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __syncthreads();
     }
-    const int next = __builtin_amdgcn_readfirstlane(*next_slot);
+    int next_v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(next_v) : "v"(slot_addr) : "memory");
+    const int next = __builtin_amdgcn_readfirstlane(next_v);
     const bool has_next = next < n_tiles;
     if (has_next) {
       UT_SETUP(next);
@@ -436,6 +506,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
   UT_STAMP(6);
   if (tid == 0 && blockIdx.x < 4096) p.stamps[blockIdx.x * 8 + 7] = tiles_done;
 #endif
+#undef UT_SLOT_WRITE
 #undef UT_SETUP
 #undef UT_FETCH
 #undef UT_FETCH_PART
@@ -445,7 +516,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
 #undef UT_CHUNK
 #undef UT_READ
 #undef UT_MFMA
+#undef UT_MFMA_STEP
 #undef UT_PIN
+#undef UT_MFMA_Q
+#undef UT_GROUP_FINE
+#undef UT_CHUNK_FINE
+#undef UT_FETCH_PIECE
 #undef UT_BARRIER
 #undef UT_MAYBE_STAGE
 }
@@ -474,6 +550,9 @@ static hipError_t launch_cfg(const ConvLaunch& c, hipStream_t s) {
   // even spacing between ranks is one chunk's MFMA time = (MI*NI) x 16 MFMAs x 64 cycles = (MI*NI) x 2 units
   ConvLaunch cl = c;
   if (c.stagger < 0) cl.stagger = grid > c.num_cu ? (BM / WR / 32) * (BN / WC / 32) * 2 : 0;
+  // stagger -2: offset co-resident workgroups by a whole tile's MFMA time / resident count, so that the per-tile
+  // epilogue + prologue of one workgroup falls into the steady state of the others instead of coinciding
+  if (c.stagger == -2 && grid > c.num_cu) cl.stagger *= c.k_pad / BK;
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, DMA>), dim3(grid), dim3(256), lds, s, cl, tiles_n, n_tiles);
   return hipGetLastError();
 }
@@ -494,6 +573,14 @@ hipError_t launch_conv_igemm(const ConvLaunch& c, hipStream_t s) {
   if (c.cout_store <= 32 && big32) return launch_cfg<256, 32, 4, 1, true>(c, s);
   if (c.cout_store <= 32) return (dma & 1) ? launch_cfg<128, 32, 4, 1, true>(c, s) : launch_cfg<128, 32, 4, 1, false>(c, s);
   if (c.cout_store <= 64) return (dma & 2) ? launch_cfg<128, 64, 2, 2, true>(c, s) : launch_cfg<128, 64, 2, 2, false>(c, s);
+  // few-tile launches (the head: 73,728 pixels = 576 tiles of 128 rows on 512 resident slots, i.e. two rounds the
+  // second of which is 12 % full): half-height tiles, three workgroups per CU
+  static const int small_m = [] { const char* e = getenv("UT_CONV_SMALL_M"); return e ? atoi(e) : 5; }();
+  {
+    const long M = (long)c.n_img * c.Ho * c.Wo;
+    const long tiles128 = ((M + 127) / 128) * ((c.cout_store + 127) / 128);
+    if (small_m > 0 && tiles128 <= (long)small_m * c.num_cu) return launch_cfg<64, 128, 1, 4, true>(c, s);
+  }
   return (dma & 4) ? launch_cfg<128, 128, 2, 2, true>(c, s) : launch_cfg<128, 128, 2, 2, false>(c, s);
 }
 

@@ -1,5 +1,7 @@
 // Diagnostic entry (not part of libumetrack_hip.so): one stride-1 3x3 convolution through launch_conv_igemm
 // with the stamp buffer attached.
+#include <stdlib.h>
+
 #include "ut_kernels.h"
 extern "C" int conv_diag(const float* in, const float* w, const float* bias, const float* res, float* out, int n_img,
                          int hw, int cin, int cout, int k_total, long long* stamps) {
@@ -9,6 +11,8 @@ extern "C" int conv_diag(const float* in, const float* w, const float* bias, con
   c.cout_store = cout; c.cout_pad = (cout + 127) / 128 * 128; c.k_total = k_total; c.k_pad = k_total;
   c.cslice = cin % 32 == 0 ? 32 : cin; c.ksize = 3; c.stride = 1; c.pad = 1; c.relu = 1; c.out_nchw = 0;
   c.num_cu = 256; c.persist_limit = 0; c.stagger = -1; c.stamps = stamps;
+  if (const char* e = getenv("UT_STAGGER")) c.stagger = atoi(e);
+  if (const char* e = getenv("UT_PERSIST_LIMIT")) c.persist_limit = atoi(e);
   static unsigned* cnt = nullptr;
   if (!cnt) (void)hipMalloc((void**)&cnt, 4);
   (void)hipMemsetAsync(cnt, 0, 4, 0);
