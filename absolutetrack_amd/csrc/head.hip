@@ -6,7 +6,7 @@
 //  ftl_out_temporal_in_kernel lib/models/feature_extractor.py:135-139, lib/models/temporal.py:51-91
 //  temporal_out_kernel        lib/models/temporal.py:87-91,133-137, lib/models/umetrack_model.py:198-210
 //  skeleton_kernel            lib/models/skeleton_encoder.py:36-53
-//  pool_decode_kernel         lib/models/model_utils.py:205-207,17-54, lib/models/regressor.py:76-121,
+//  pool_matvec + decode       lib/models/model_utils.py:205-207,17-54, lib/models/regressor.py:76-121,
 //                             lib/models/umetrack_model.py:77-97
 #include "ut_kernels.h"
 #include "ut_math.h"
@@ -171,14 +171,13 @@ __global__ __launch_bounds__(192) void skeleton_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------- pool + output conv + decode
-__global__ __launch_bounds__(128) void pool_decode_kernel(HeadArgs a, const float* __restrict__ reg_feat,
-                                                          int reg_c, const float* __restrict__ w,
-                                                          const float* __restrict__ bias, int d,
-                                                          float* __restrict__ out_pose,
-                                                          float* __restrict__ out_raw) {
+// Global average pool + the regressor's final 1x1 convolution (commuted: the pool is linear), one block per
+// sample: raw [S,64] (d valid entries, rest 0).
+__global__ __launch_bounds__(128) void pool_matvec_kernel(const float* __restrict__ reg_feat, int reg_c,
+                                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                                          int d, float* __restrict__ raw_out) {
   const int s = blockIdx.x;
   __shared__ float pooled[80];
-  __shared__ float raw[64];
   const float* f = reg_feat + (size_t)s * PIX * reg_c;
   if (threadIdx.x < reg_c) {
     float acc = 0.f;
@@ -186,30 +185,44 @@ __global__ __launch_bounds__(128) void pool_decode_kernel(HeadArgs a, const floa
     pooled[threadIdx.x] = acc * (1.0f / 36.0f);
   }
   __syncthreads();
-  if (threadIdx.x < d) {
-    float acc = 0.f;
-    for (int c = 0; c < reg_c; ++c) acc = fmaf(w[threadIdx.x * reg_c + c], pooled[c], acc);
-    raw[threadIdx.x] = acc + bias[threadIdx.x];
+  if (threadIdx.x < 64) {
+    float v = 0.f;
+    if (threadIdx.x < d) {
+      float acc = 0.f;
+      for (int c = 0; c < reg_c; ++c) acc = fmaf(w[threadIdx.x * reg_c + c], pooled[c], acc);
+      v = acc + bias[threadIdx.x];
+    }
+    raw_out[(size_t)s * 64 + threadIdx.x] = v;
   }
-  __syncthreads();
+}
+
+// Decoders (lib/models/regressor.py:76-121) + Procrustes alignment (lib/models/model_utils.py:17-54) + world
+// transform (lib/models/umetrack_model.py:77-97), one THREAD per sample: the float64 Kabsch chain is serial, so
+// 64 samples share a wave instead of one lane of a wave each.
+__global__ __launch_bounds__(64) void decode_kernel(HeadArgs a, const float* __restrict__ raw_in, int d,
+                                                    float* __restrict__ out_pose) {
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= a.n_samples) return;
+  const float* raw = raw_in + (size_t)s * 64;
   float* o = out_pose + (size_t)s * 60;
-  if (out_raw && threadIdx.x < 64) out_raw[(size_t)s * 64 + threadIdx.x] = threadIdx.x < d ? raw[threadIdx.x] : 0.f;
   // joint angles: 20 finger DoF + 2 zero wrist angles
-  if (threadIdx.x < 22) o[threadIdx.x] = threadIdx.x < 20 ? raw[threadIdx.x] : 0.f;
+  for (int k = 0; k < 22; ++k) o[k] = k < 20 ? raw[k] : 0.f;
   // sigmas: clamp(softplus(x), 1e-5)
   const int sig0 = (d == 63) ? 42 : 41;
-  if (threadIdx.x >= 32 && threadIdx.x < 32 + 21) {
-    float x = raw[sig0 + threadIdx.x - 32];
-    float sp = x > 20.f ? x : log1pf(expf(x));
-    o[39 + threadIdx.x - 32] = fmaxf(sp, 1e-5f);
+  for (int k = 0; k < 21; ++k) {
+    const float x = raw[sig0 + k];
+    const float sp = x > 20.f ? x : log1pf(expf(x));
+    o[39 + k] = fmaxf(sp, 1e-5f);
   }
-  if (threadIdx.x == 64) o[38] = (d == 63) ? expf(raw[41]) : 0.f;
-  if (threadIdx.x == 96) {
+  o[38] = (d == 63) ? expf(raw[41]) : 0.f;
+  {
     // fixed source points (lib/models/regressor.py:19-47)
     const double k = 0.1, q = 0.1 / 1.4142135623730951;
     const double src[7][3] = {{0, 0, 0}, {k, 0, 0}, {0, k, 0}, {0, 0, k}, {-q, -q, 0}, {-q, 0, -q}, {0, -q, -q}};
     double dst[7][3], ms[3] = {0, 0, 0}, md[3] = {0, 0, 0};
+#pragma unroll
     for (int i = 0; i < 7; ++i)
+#pragma unroll
       for (int j = 0; j < 3; ++j) {
         dst[i][j] = (double)raw[20 + 3 * i + j];
         // the reference holds the source points in fp32
@@ -218,13 +231,18 @@ __global__ __launch_bounds__(128) void pool_decode_kernel(HeadArgs a, const floa
       }
     for (int j = 0; j < 3; ++j) { ms[j] /= 7.0; md[j] /= 7.0; }
     double h[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
     for (int i = 0; i < 7; ++i)
+#pragma unroll
       for (int r = 0; r < 3; ++r)
+#pragma unroll
         for (int c = 0; c < 3; ++c) h[r][c] += ((double)(float)src[i][r] - ms[r]) * (dst[i][c] - md[c]);
     double rot[3][3];
     kabsch_rotation(h, rot);
     double xf[16] = {0};
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
+#pragma unroll
       for (int j = 0; j < 3; ++j) xf[4 * i + j] = rot[i][j];
       xf[4 * i + 3] = md[i] - (rot[i][0] * ms[0] + rot[i][1] * ms[1] + rot[i][2] * ms[2]);
     }
@@ -261,9 +279,10 @@ hipError_t launch_skeleton(const float* skel_in, const float* w, const float* bi
   return hipGetLastError();
 }
 hipError_t launch_pool_decode(const HeadArgs& a, const float* reg_feat, int reg_c, const float* w,
-                              const float* bias, int d, float* out_pose, float* out_raw, hipStream_t s) {
-  hipLaunchKernelGGL(pool_decode_kernel, dim3(a.n_samples), dim3(128), 0, s, a, reg_feat, reg_c, w, bias, d,
-                     out_pose, out_raw);
+                              const float* bias, int d, float* out_pose, float* out_raw, float* raw_ws, hipStream_t s) {
+  float* raw = out_raw ? out_raw : raw_ws;     // [S,64]
+  hipLaunchKernelGGL(pool_matvec_kernel, dim3(a.n_samples), dim3(128), 0, s, reg_feat, reg_c, w, bias, d, raw);
+  hipLaunchKernelGGL(decode_kernel, dim3((a.n_samples + 63) / 64), dim3(64), 0, s, a, raw, d, out_pose);
   return hipGetLastError();
 }
 

@@ -85,7 +85,7 @@ hipError_t launch_skeleton(const float* skel_in /*[n_skel,2,22,3]*/, const float
 // avgpool(6x6) -> 1x1 conv (C->D) -> decode -> world transform -> pose record [S,60]
 hipError_t launch_pool_decode(const HeadArgs& a, const float* reg_feat /*[S,36,C]*/, int reg_c,
                               const float* w /*[D][C]*/, const float* bias /*[D]*/, int d,
-                              float* out_pose, float* out_raw, hipStream_t s);
+                              float* out_pose, float* out_raw, float* raw_ws /*[S,64] scratch*/, hipStream_t s);
 
 hipError_t launch_fk(const float* hand_model, int n_models, const float* ja, int ja_stride,
                      const float* xf, int xf_stride, const int64_t* mirror, float t_scale, int n,

@@ -12,28 +12,47 @@ namespace ut {
 
 // ---------------------------------------------------------------- small dense helpers (fp64)
 UT_HD inline bool inv4(const double* a, double* out) {
-  // Gauss-Jordan with partial pivoting on [a | I]
+  // Gauss-Jordan with partial pivoting on [a | I].  Every index is a compile-time constant after unrolling (the
+  // pivot row is swapped in by predicated exchanges), so on the GPU the 4x8 tableau lives in registers and not
+  // in scratch memory.
   double m[4][8];
+#pragma unroll
   for (int i = 0; i < 4; ++i)
+#pragma unroll
     for (int j = 0; j < 4; ++j) { m[i][j] = a[4 * i + j]; m[i][4 + j] = (i == j) ? 1.0 : 0.0; }
   bool ok = true;
+#pragma unroll
   for (int c = 0; c < 4; ++c) {
     int piv = c;
     double best = fabs(m[c][c]);
+#pragma unroll
     for (int r = c + 1; r < 4; ++r)
       if (fabs(m[r][c]) > best) { best = fabs(m[r][c]); piv = r; }
     if (best == 0.0) ok = false;
-    if (piv != c)
-      for (int j = 0; j < 8; ++j) { double t = m[c][j]; m[c][j] = m[piv][j]; m[piv][j] = t; }
-    double d = 1.0 / m[c][c];
+#pragma unroll
+    for (int r = c + 1; r < 4; ++r) {
+      const bool sw = (piv == r);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const double x = m[c][j], y = m[r][j];
+        m[c][j] = sw ? y : x;
+        m[r][j] = sw ? x : y;
+      }
+    }
+    const double d = 1.0 / m[c][c];
+#pragma unroll
     for (int j = 0; j < 8; ++j) m[c][j] *= d;
+#pragma unroll
     for (int r = 0; r < 4; ++r)
       if (r != c) {
-        double f = m[r][c];
+        const double f = m[r][c];
+#pragma unroll
         for (int j = 0; j < 8; ++j) m[r][j] -= f * m[c][j];
       }
   }
+#pragma unroll
   for (int i = 0; i < 4; ++i)
+#pragma unroll
     for (int j = 0; j < 4; ++j) out[4 * i + j] = m[i][4 + j];
   return ok;
 }
@@ -57,23 +76,30 @@ UT_HD inline void jacobi_eig3(double a[3][3], double v[3][3]) {
     for (int j = 0; j < 3; ++j) v[i][j] = (i == j);
   for (int sweep = 0; sweep < 12; ++sweep) {
     double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
-    if (off < 1e-300) break;
+    // converged: the off-diagonal mass is below 1e-40 of the diagonal's, further rotations are exact identities
+    // in double precision (Jacobi converges quadratically: 1e-3 -> 1e-6 -> 1e-12 -> 1e-24 -> 1e-48)
+    if (off < 1e-300 || off < 1e-40 * (fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]))) break;
+#pragma unroll
     for (int p = 0; p < 2; ++p)
+#pragma unroll
       for (int q = p + 1; q < 3; ++q) {
         if (a[p][q] == 0.0) continue;
         double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
         double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
         double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+#pragma unroll
         for (int k = 0; k < 3; ++k) {           // A <- A J
           double akp = a[k][p], akq = a[k][q];
           a[k][p] = c * akp - sn * akq;
           a[k][q] = sn * akp + c * akq;
         }
+#pragma unroll
         for (int k = 0; k < 3; ++k) {           // A <- J^T A
           double apk = a[p][k], aqk = a[q][k];
           a[p][k] = c * apk - sn * aqk;
           a[q][k] = sn * apk + c * aqk;
         }
+#pragma unroll
         for (int k = 0; k < 3; ++k) {
           double vkp = v[k][p], vkq = v[k][q];
           v[k][p] = c * vkp - sn * vkq;
@@ -95,14 +121,21 @@ UT_HD inline void kabsch_rotation(const double h[3][3], double r[3][3]) {
       ata[i][j] = s;
     }
   jacobi_eig3(ata, v);
-  int idx[3] = {0, 1, 2};
+  // columns sorted by descending eigenvalue: a three-element compare-exchange network on (value, column) pairs,
+  // stable like the index sort it replaces (exchange only on strictly greater), all indices static
   double ev[3] = {ata[0][0], ata[1][1], ata[2][2]};
-  for (int i = 0; i < 2; ++i)
-    for (int j = i + 1; j < 3; ++j)
-      if (ev[idx[j]] > ev[idx[i]]) { int t = idx[i]; idx[i] = idx[j]; idx[j] = t; }
-  double vs[3][3];   // columns sorted by descending singular value
+  double vs[3][3];
+#pragma unroll
   for (int c = 0; c < 3; ++c)
-    for (int k = 0; k < 3; ++k) vs[k][c] = v[k][idx[c]];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vs[k][c] = v[k][c];
+#define UT_CMPX(I, J)                                                         \
+  if (ev[J] > ev[I]) {                                                        \
+    double t_ = ev[I]; ev[I] = ev[J]; ev[J] = t_;                             \
+    for (int k = 0; k < 3; ++k) { t_ = vs[k][I]; vs[k][I] = vs[k][J]; vs[k][J] = t_; } \
+  }
+  UT_CMPX(0, 1) UT_CMPX(0, 2) UT_CMPX(1, 2)
+#undef UT_CMPX
   double u[3][3];
   for (int c = 0; c < 2; ++c) {
     double n2 = 0;

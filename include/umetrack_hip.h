@@ -61,8 +61,8 @@ const char* ut_last_error(ut_handle h);   /* h may be NULL: error of the last fa
  * (needed before capturing calls into a hipGraph). */
 int ut_reserve(ut_handle h, int max_crops, int max_samples, int max_slots);
 
-/* Crops processed per backbone pass (activations of one pass stay resident in L2/Infinity
- * Cache).  0 = library default. */
+/* Crops processed per pass of the early (48x48, 24x24) backbone layers; 0 = library default
+ * (4096), at most 7281 (32-bit buffer offsets).  Workspace grows with it: ~1 MB per crop. */
 int ut_set_backbone_chunk(ut_handle h, int crops_per_pass);
 
 /* lib/tracker/tracker.py:61-89 (_warp_image) + :332 (/255) for a batch of crops.

@@ -227,3 +227,21 @@ def test_warp_identity_property(engine):
     assert (got != want).mean() < 2e-3
     # the optical axis maps to the principal point: centre 2x2 block samples the 4 source pixels around (317.5,239.5)
     assert abs(got[47:49, 47:49].mean() * 255 - src[0, 239:241, 317:319].mean()) < 1.0
+
+
+def test_batches_beyond_one_pass(engine):
+    """More crops than one phase-A pass (4096) and than one phase-B pass (8192): the passes tile the batch and the
+    result equals the per-slice results bit for bit; the chunk bound set by the 32-bit buffer offsets is enforced."""
+    n = 8192 + 4096 + 37
+    g = torch.Generator(device=DEV)
+    g.manual_seed(11)
+    crops = torch.randint(0, 256, (n, 96, 96), device=DEV, generator=g, dtype=torch.uint8).float() / 255.0
+    full = engine.backbone(crops)
+    assert torch.isfinite(full).all()
+    for lo, hi in ((0, 64), (4090, 4100), (8185, 8200), (n - 37, n)):
+        assert torch.equal(engine.backbone(crops[lo:hi]), full[lo:hi])
+    with pytest.raises(RuntimeError):
+        engine.set_backbone_chunk(7282)
+    engine.set_backbone_chunk(7281)
+    assert torch.equal(engine.backbone(crops[:7300]), full[:7300])
+    engine.set_backbone_chunk(0)
