@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ cro
                                                    const float* __restrict__ w,
                                                    const float* __restrict__ bias,
                                                    float* __restrict__ out, int n) {
-  __shared__ float tile[IN_ROWS][IN_COLS + 2];
+  __shared__ __attribute__((aligned(8))) float tile[IN_ROWS][IN_COLS + 2];   // row stride 100 floats: 8-byte pairs stay aligned
   __shared__ float ws[STEM_C * 9 + STEM_C];
   const int img = blockIdx.y;
   const int prow0 = blockIdx.x * ROWS_PER_WG;
@@ -29,20 +29,30 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ cro
     tile[r][c] = (y >= 0 && y < CROP && x >= 0 && x < CROP) ? src[y * CROP + x] : 0.f;
   }
   __syncthreads();
-  // 4 rows x 48 pooled pixels x 8 channel groups = 1536 work items, 6 per thread
+  // 4 rows x 48 pooled pixels x 8 channel groups = 1536 work items, 6 per thread.  A thread's channel group
+  // (item & 7 == tid & 7) is the same for all of them: its 4 x 9 weights and 4 biases live in registers, and
+  // the 4x4 input window is read as 8-byte pairs - the kernel is bound by VALU/LDS issue, not by HBM.
+  const int cg = threadIdx.x & 7;
+  float wr[4][9], br[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[k][t] = ws[(cg * 4 + k) * 9 + t];
+    br[k] = ws[STEM_C * 9 + cg * 4 + k];
+  }
   for (int item = threadIdx.x; item < ROWS_PER_WG * POOLED * 8; item += 256) {
-    const int cg = item & 7;
     const int pix = item >> 3;
     const int pr = pix / POOLED, pc = pix - pr * POOLED;
     float in[4][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) in[a][b] = tile[2 * pr + a][2 * pc + b];
+    for (int a = 0; a < 4; ++a) {
+      const float2 lo = *reinterpret_cast<const float2*>(&tile[2 * pr + a][2 * pc]);
+      const float2 hi = *reinterpret_cast<const float2*>(&tile[2 * pr + a][2 * pc + 2]);
+      in[a][0] = lo.x; in[a][1] = lo.y; in[a][2] = hi.x; in[a][3] = hi.y;
+    }
     float res[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float* wk = ws + (cg * 4 + k) * 9;
       float best = -3.4e38f;
 #pragma unroll
       for (int dy = 0; dy < 2; ++dy)
@@ -52,10 +62,10 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ cro
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) acc = fmaf(in[dy + ky][dx + kx], wk[ky * 3 + kx], acc);
+            for (int kx = 0; kx < 3; ++kx) acc = fmaf(in[dy + ky][dx + kx], wr[k][ky * 3 + kx], acc);
           best = fmaxf(best, acc);
         }
-      res[k] = fmaxf(best + ws[STEM_C * 9 + cg * 4 + k], 0.f);
+      res[k] = fmaxf(best + br[k], 0.f);
     }
     float* o = out + (((size_t)img * POOLED + prow0 + pr) * POOLED + pc) * STEM_C + cg * 4;
     *reinterpret_cast<float4*>(o) = make_float4(res[0], res[1], res[2], res[3]);
