@@ -167,7 +167,7 @@ def gen_crop_cameras(cam_params: torch.Tensor, camera_angles: torch.Tensor, hand
                      joint_limits: torch.Tensor, joint_angles: torch.Tensor, wrist_xf: torch.Tensor,
                      frame_idx: torch.Tensor, hand_idx: torch.Tensor, n_cams: int, src_wh: Tuple[int, int],
                      max_views: int = 2, min_vis: int = 19, crop_size: int = arch.CROP,
-                     focal_multiplier: float = 0.8) -> Dict[str, torch.Tensor]:
+                     focal_multiplier: float = 0.8, check_indices: bool = True) -> Dict[str, torch.Tensor]:
     """ut_gen_crop_cameras: crop cameras of n (frame, hand) label poses in one launch, padded to max_views.
     Returns crop_params [n,V,24] f64, intrinsics [n,V,3,3], extrinsics [n,V,4,4], cam_index [n,V] i32,
     n_views [n] i32, status [n] i32.  All tensors on one HIP device; no CPU fallback."""
@@ -190,7 +190,8 @@ def gen_crop_cameras(cam_params: torch.Tensor, camera_angles: torch.Tensor, hand
         raise ValueError("gen_crop_cameras: hand_model / joint_limits must hold 1 or n models")
     if camera_angles.shape[0] != n_cams or cam_params.shape[0] % n_cams:
         raise ValueError("gen_crop_cameras: cam_params rows must be a multiple of n_cams = len(camera_angles)")
-    if n and (int(frame_idx.max()) + 1) * n_cams > cam_params.shape[0]:
+    # (reads frame_idx back: pass check_indices=False when the same index tensor was validated before)
+    if check_indices and n and (int(frame_idx.max()) + 1) * n_cams > cam_params.shape[0]:
         raise ValueError("gen_crop_cameras: frame_idx points past cam_params")
     out = {"crop_params": torch.zeros(n, max_views, 24, dtype=torch.float64, device=d),
            "intrinsics": torch.zeros(n, max_views, 3, 3, dtype=torch.float32, device=d),

@@ -177,6 +177,47 @@ def crop_plan_on_device(lab: Dict[str, np.ndarray], hand_model: HandModel, frame
             "hand_idx": hand_idx[keep]}
 
 
+class DeviceCropPlanner:
+    """Row f1 inside the step: the label poses of a frame block stay on the GPU and every call regenerates the
+    crop cameras with one ut_gen_crop_cameras launch and no host round trip, like the reference's per-frame loop
+    calls gen_crop_cameras before track_frame (run_eval_known_skeleton.py:70-81).  The padded [S, 2] output is the
+    compact one when every candidate has two views; `ok` (a device flag) says whether that held and no candidate
+    was unbuildable - read it after the timed region."""
+
+    def __init__(self, lab: Dict[str, np.ndarray], hand_model: HandModel, frame_ids: Sequence[int], device,
+                 opts: Optional[HandTrackerOpts] = None):
+        self.opts = opts or HandTrackerOpts()
+        dev = torch.device(device)
+        c = label_candidates(lab, frame_ids)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        self.n_cams, self.src_wh = c["n_cams"], c["src_wh"]
+        self.cam_params, self.camera_angles = t(c["cam_params"]), t(c["camera_angles"])
+        self.joint_angles, self.wrist_xf = t(c["joint_angles"]), t(c["wrist_xf"])
+        self.frame_idx, self.hand_idx = t(c["frame_idx"]), t(c["hand_idx"])
+        self.blob = torch.from_numpy(_native.hand_model_blob(
+            hand_model.joint_rotation_axes, hand_model.joint_rest_positions, hand_model.landmark_rest_positions,
+            hand_model.landmark_rest_bone_weights, hand_model.landmark_rest_bone_indices)).reshape(1, 321).to(dev)
+        self.limits = hand_model.joint_limits.float().to(dev)
+        if int(self.frame_idx.max()) * self.n_cams + self.n_cams > self.cam_params.shape[0]:
+            raise ValueError("frame_idx points past cam_params")
+        self._src_base = self.frame_idx.long()[:, None] * self.n_cams
+        self.ok = torch.ones((), dtype=torch.bool, device=dev)
+
+    def refresh(self, batch: FrameBatch) -> FrameBatch:
+        """Overwrite the crop-camera tensors of an all-two-view batch in place from a fresh launch."""
+        g = _native.gen_crop_cameras(self.cam_params, self.camera_angles, self.blob, self.limits, self.joint_angles,
+                                     self.wrist_xf, self.frame_idx, self.hand_idx, self.n_cams, self.src_wh,
+                                     max_views=MAX_VIEW_NUM, min_vis=self.opts.min_required_vis_landmarks,
+                                     crop_size=arch.CROP, focal_multiplier=self.opts.hand_ratio_in_crop,
+                                     check_indices=False)
+        self.ok = self.ok & (g["n_views"] == MAX_VIEW_NUM).all() & (g["status"] == 0).all()
+        batch.crop_params.copy_(g["crop_params"].reshape(-1, 24))
+        batch.intrinsics.copy_(g["intrinsics"].reshape(-1, 3, 3))
+        batch.extrinsics.copy_(g["extrinsics"].reshape(-1, 4, 4))
+        batch.src_index.copy_((self._src_base + g["cam_index"].long().clamp_(min=0)).reshape(-1).int())
+        return batch
+
+
 def make_batch(plan: dict, src_u8: torch.Tensor, device, independent_frames: bool = True) -> FrameBatch:
     """independent_frames: every hand-sample owns a temporal slot and starts without memory
     (`memory_idx=arange(S)`, `use_memory=False`, the throughput configuration of SURVEY.md section 8 d)."""

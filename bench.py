@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="crops per backbone pass (0 = library default)")
     ap.add_argument("--cpu-frames", type=int, default=768, help="label frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cropgen-in-step", action="store_true",
+                    help="also regenerate the crop cameras from the label poses inside every step (SURVEY 8 f1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -71,7 +73,8 @@ def main():
 
     f_local = args.frames_per_gpu
     lo, hi = pipeline.shard_frames(f_local * world, rank, world)
-    plan = pipeline.crop_plan_from_labels(lab, hm, range(lo, hi))
+    plan = {k: v.cpu().numpy() for k, v in pipeline.crop_plan_on_device(lab, hm, range(lo, hi), device).items()}
+    planner = pipeline.DeviceCropPlanner(lab, hm, range(lo, hi), device) if args.cropgen_in_step else None
     gen = torch.Generator(device=device)
     gen.manual_seed(1234 + rank)
     src = torch.randint(0, 256, (f_local * 4, 480, 636), dtype=torch.uint8, device=device, generator=gen)
@@ -84,6 +87,8 @@ def main():
             dist.barrier()
 
     def one_step():
+        if planner is not None:
+            planner.refresh(batch)
         rec = hot.step(batch)
         return pipeline.gather_records(rec, world)
 
@@ -105,6 +110,8 @@ def main():
         dt = float(t.item())
     assert out.shape == (s_local * world, pipeline.RECORD)
     finite = bool(torch.isfinite(out).all().item())
+    if planner is not None and not bool(planner.ok.item()):
+        raise SystemExit("crop-camera generation inside the step produced a candidate without two views")
 
     total_hf = s_local * world * args.steps
     value = total_hf / dt
@@ -150,7 +157,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "4 fisheye cameras x 2 hands per frame, 2 views per hand, 96x96 crops, "
                                    f"{'known' if known else 'unknown'}-skeleton path, full hot path "
-                                   "(resample+backbone+head+FK) + all-gather of records",
+                                   "(resample+backbone+head+FK) + all-gather of records"
+                                   + (", crop cameras regenerated in the step" if planner is not None else ""),
                        "frames_per_gpu": f_local, "hand_frames_per_step": s_local * world,
                        "crops_per_step": n_local * world, "src_image": "480x636 u8 x 4 cameras",
                        "parallelism": f"frame-shard x{world}", "outputs_finite": finite},

@@ -168,3 +168,28 @@ def test_argument_checks(labels, hand_model):
     assert lib.ut_gen_crop_cameras(None, None, None, None, None, 1, None, None, None, None, 4, 4, 2, 19, 636, 480, 96,
                                    0.8, None, None, None, None, None, None, None) != 0
     assert b"ut_gen_crop_cameras" in lib.ut_last_error(None)
+
+
+def test_planner_refreshes_a_batch_in_place(labels, hand_model):
+    """DeviceCropPlanner (crop cameras regenerated inside the step, no host round trip) rewrites exactly what
+    crop_plan_on_device produced for the same frames."""
+    frames = list(range(20, 60))
+    plan = {k: v.cpu().numpy() for k, v in pipeline.crop_plan_on_device(labels, hand_model, frames, DEV).items()}
+    src = torch.zeros(len(frames) * 4, 480, 636, dtype=torch.uint8)
+    batch = pipeline.make_batch(plan, src, DEV)
+    want = {k: getattr(batch, k).clone() for k in ("crop_params", "intrinsics", "extrinsics", "src_index")}
+    for k in want:
+        getattr(batch, k).zero_()
+    planner = pipeline.DeviceCropPlanner(labels, hand_model, frames, DEV)
+    planner.refresh(batch)
+    torch.cuda.synchronize()
+    assert bool(planner.ok.item())
+    for k, w in want.items():
+        assert torch.equal(getattr(batch, k), w), k
+    # a pose no camera sees: the flag drops, nothing faults
+    c2w = labels["camera_to_world_transforms"][frames[0]]
+    fwd = c2w[:, :3, 2].mean(0)
+    behind = c2w[:, :3, 3].mean(0) - 1000.0 * fwd / np.linalg.norm(fwd)
+    planner.wrist_xf[0, :3, 3] = torch.from_numpy(behind.astype(np.float32)).to(DEV)
+    planner.refresh(batch)
+    assert not bool(planner.ok.item())
