@@ -121,6 +121,27 @@ def fk_device() -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
 
+_BLOB_FIELDS = ("joint_rotation_axes", "joint_rest_positions", "landmark_rest_positions", "landmark_rest_bone_weights",
+                "landmark_rest_bone_indices")
+_blob_cache: list = []      # [(key, tensors kept alive, device blob)], most recent first
+
+
+def device_blob(hand_model: HandModel, dev: torch.device) -> torch.Tensor:
+    """The packed [n_models, 321] fp32 model the FK / crop-camera kernels read, cached on the device: the per-frame
+    API skins the same HandModel several times per frame.  Keyed on tensor identity + in-place version counters."""
+    tensors = tuple(getattr(hand_model, f) for f in _BLOB_FIELDS)
+    key = (str(dev),) + tuple((id(t), t._version) for t in tensors)
+    for i, (k, _keep, blob) in enumerate(_blob_cache):
+        if k == key:
+            if i:
+                _blob_cache.insert(0, _blob_cache.pop(i))
+            return blob
+    blob = torch.from_numpy(_native.hand_model_blob(*tensors).reshape(-1, 321)).to(dev)
+    _blob_cache.insert(0, (key, tensors, blob))
+    del _blob_cache[8:]
+    return blob
+
+
 def skin_landmarks(hand_model: HandModel, joint_angles: torch.Tensor, wrist_transforms: torch.Tensor) -> torch.Tensor:
     """[...,22] joint angles + [...,4,4] wrist transforms -> [...,21,3] landmarks, any leading dims; the
     model's tensors are either unbatched or carry the same leading dims (lib/common/hand_skinning.py:189-209)."""
@@ -131,10 +152,7 @@ def skin_landmarks(hand_model: HandModel, joint_angles: torch.Tensor, wrist_tran
         raise AssertionError(f"Leading dimensions do not match, got {lead} and {model_lead}")
     src_device = joint_angles.device
     dev = src_device if src_device.type == "cuda" else fk_device()
-    blob = _native.hand_model_blob(hand_model.joint_rotation_axes, hand_model.joint_rest_positions,
-                                   hand_model.landmark_rest_positions, hand_model.landmark_rest_bone_weights,
-                                   hand_model.landmark_rest_bone_indices).reshape(-1, 321)
-    out = _native.fk_stateless(torch.from_numpy(blob).to(dev),
+    out = _native.fk_stateless(device_blob(hand_model, dev),
                                joint_angles.reshape(n, 22).to(dev, torch.float32),
                                wrist_transforms.reshape(n, 4, 4).to(dev, torch.float32))
     return out.reshape(lead + (21, 3)).to(src_device)

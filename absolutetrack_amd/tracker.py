@@ -177,6 +177,9 @@ class HandTracker:
                          gt_tracking: Dict[int, SingleHandPose], min_num_crops: int
                          ) -> Dict[int, Dict[int, PinholePlaneCameraModel]]:
         crop_cameras: Dict[int, Dict[int, PinholePlaneCameraModel]] = {}
+        hands = [(h, p) for h, p in (gt_tracking or {}).items() if p.hand_confidence >= CONFIDENCE_THRESHOLD]
+        if hands and self._device == "cuda" and self._batched_cropgen_ok(cameras, hand_model):
+            return self._gen_crop_cameras_batched(cameras, camera_angles, hand_model, hands, min_num_crops)
         for hand_idx, pose in (gt_tracking or {}).items():
             if pose.hand_confidence < CONFIDENCE_THRESHOLD:
                 continue
@@ -184,6 +187,52 @@ class HandTracker:
                 cameras, camera_angles, hand_model, pose, hand_idx, self._num_crop_points, self._input_size,
                 max_view_num=MAX_VIEW_NUM, sort_camera_index=True, focal_multiplier=self._hand_ratio_in_crop,
                 mirror_right_hand=True, min_required_vis_landmarks=self._min_required_vis_landmarks)
+            if per_hand and len(per_hand) >= min_num_crops:
+                crop_cameras[hand_idx] = per_hand
+        return crop_cameras
+
+    def _batched_cropgen_ok(self, cameras, hand_model) -> bool:
+        """ut_gen_crop_cameras covers the configuration the eval scripts use: 63 crop points, square crops, Fisheye62
+        source cameras of one size, an unbatched hand model with joint limits."""
+        return (self._num_crop_points == 63 and self._input_size[0] == self._input_size[1] and len(cameras) > 0
+                and all(isinstance(c, geometry.Fisheye62CameraModel) for c in cameras)
+                and len({(c.width, c.height) for c in cameras}) == 1
+                and hand_model.joint_limits is not None and hand_model.joint_rest_positions.dim() == 2)
+
+    def _gen_crop_cameras_batched(self, cameras, camera_angles, hand_model, hands, min_num_crops):
+        """All hands of the frame through one ut_gen_crop_cameras launch (lib/tracker/tracker.py:222-260)."""
+        from .hand import device_blob
+        dev = torch.device("cuda", torch.cuda.current_device())
+        n = len(hands)
+        up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+        cam_rows = np.stack([geometry.pack_camera_model(c) for c in cameras])
+        g = _native.gen_crop_cameras(
+            up(cam_rows, np.float64), up(np.asarray(camera_angles), np.float64), device_blob(hand_model, dev),
+            hand_model.joint_limits.float().to(dev),
+            up(np.stack([np.asarray(p.joint_angles) for _h, p in hands]), np.float32),
+            up(np.stack([np.asarray(p.wrist_xform) for _h, p in hands]), np.float32),
+            torch.zeros(n, dtype=torch.int32, device=dev), up(np.array([h for h, _p in hands]), np.int64),
+            len(cameras), (cameras[0].width, cameras[0].height), max_views=MAX_VIEW_NUM,
+            min_vis=self._min_required_vis_landmarks, crop_size=int(self._input_size[0]),
+            focal_multiplier=self._hand_ratio_in_crop, check_indices=False)
+        packed = torch.cat([g["crop_params"].reshape(n, -1), g["cam_index"].double(), g["n_views"].double()[:, None],
+                            g["status"].double()[:, None]], 1).cpu().numpy()        # one read-back
+        crop_cameras: Dict[int, Dict[int, PinholePlaneCameraModel]] = {}
+        size = int(self._input_size[0])
+        for i, (hand_idx, _pose) in enumerate(hands):
+            rows = packed[i, : MAX_VIEW_NUM * 24].reshape(MAX_VIEW_NUM, 24)
+            cam_index = packed[i, MAX_VIEW_NUM * 24: MAX_VIEW_NUM * 25].astype(int)
+            n_views, status = int(packed[i, -2]), int(packed[i, -1])
+            if status != 0:
+                raise ValueError("Unable to create crop camera")
+            per_hand = {}
+            for v in range(n_views):
+                t = np.eye(4)
+                t[:3, :3] = rows[v, 4:13].reshape(3, 3)
+                t[:3, 3] = rows[v, 13:16]
+                per_hand[int(cam_index[v])] = PinholePlaneCameraModel(
+                    width=size, height=size, f=(rows[v, 0], rows[v, 1]), c=(rows[v, 2], rows[v, 3]), distort_coeffs=[],
+                    camera_to_world_xf=t)
             if per_hand and len(per_hand) >= min_num_crops:
                 crop_cameras[hand_idx] = per_hand
         return crop_cameras
