@@ -8,22 +8,27 @@
 // channel) - see ut_kernels.h.  Activations are NHWC so a k-run of 4 channels is one 16-byte load;
 // weights are pre-packed [cout_pad][k_pad] (k contiguous) with BatchNorm folded in.
 //
-// A workgroup (4 waves, 256 threads) computes BM x BN output tiles and walks K in chunks of 32:
-//   buffer loads (im2col gather; out-of-image taps get an out-of-range offset and read as 0, so the load
-//   path has no branches) -> registers -> LDS (double buffered, rows padded to 36 floats so that the
-//   ds_read_b128 fragment reads are bank-conflict free) -> 4 MFMA 32x32x2 per fragment pair.
+// A workgroup (4 waves, 256 threads) computes BM x BN output tiles and walks K in chunks of 32.  Operands go
+// global -> LDS directly (buffer_load_dwordx4 ... lds, 1 KB per wave-instruction): the im2col gather for the
+// pixels, plain rows for the weights; out-of-image taps and rows beyond M get an out-of-range buffer offset and
+// arrive as zeros, so the load path has no branches.  LDS rows are 128 B, unpadded, their 16-byte chunks
+// XOR-swizzled by (row >> 1) & 7 on the SOURCE side (which chunk a lane fetches), which makes the ds_read_b128
+// fragment reads conflict free under gfx950's 16-lane read groups.  Two stages, one barrier per chunk.  (The
+// register-staged variant DMA = false, rows padded to 36 floats, is kept for comparison: UT_CONV_DMA.)
 // Lane l of a wave holds row (l&31) of the fragment and k-half (l>>5); the 4 floats of a b128 read feed
 // 4 consecutive MFMAs (the k order inside the 8-run is permuted identically for A and B).
 //
-// Workgroups are PERSISTENT: a grid of (CUs x resident blocks) walks the tile list, and the first chunk,
-// bias and residual of the next tile are fetched under the last chunk of the current one.  A 64-cycle MFMA
-// makes operand traffic cheap; what costs throughput is every cycle the matrix pipe waits for a tile
-// prologue (index math, first-touch HBM latency, residual fetch), and co-resident workgroups with equal
-// work fall into lockstep so that their prologues coincide.  With the prologue hidden the per-tile bubble
-// is the accumulator drain + store issue only.
+// Workgroups are PERSISTENT: a grid of (CUs x resident workgroups) takes tiles from a device-wide queue (first
+// round: static XCD-contiguous slots; afterwards one atomic ticket per workgroup per tile, requested a tile
+// ahead by wave 0 and handed to the other waves through an LDS word), and the first chunk, bias and residual of
+// the next tile are fetched under the last chunk of the current one.  A 64-cycle MFMA makes operand traffic
+// cheap; what costs throughput is every cycle the matrix pipe waits for a tile prologue (index math,
+// first-touch latency, residual fetch) or for a store-bound epilogue.
 // Accumulators start at bias (+ residual); epilogue = (ReLU) + store.  The weights are the MFMA "A" operand
 // and the pixels the "B" operand, so in the C layout (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
 // a lane owns one pixel and register quads are 4 consecutive channels: 16-byte NHWC loads and stores.
+// Tile shapes: 128x128 (cout > 64), 128x64 (cout <= 64, three workgroups per CU), 64x128 for launches with few
+// tiles (projection and head: 74 k pixels); layer1 (3x3, 32 -> 32) runs in conv_patch.hip instead.
 #include <stdlib.h>
 
 #include "ut_kernels.h"
@@ -209,36 +214,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
   }
 #define UT_FETCH(DSTBUF) { UT_FETCH_PART(0, DSTBUF); UT_FETCH_PART(1, DSTBUF); UT_FETCH_PART(2, DSTBUF); }
 
-  // Finer interleave (UT_FINE_FETCH): one 1-KB piece in front of every MFMA quad instead of three bursts.
-  // The per-chunk tap arithmetic is done with piece 0 and kept in f_tap_off / f_dst.
-  int f_tap_off = 0, f_dy = 0, f_dx = 0;
-  unsigned f_dst = 0;
-#define UT_FETCH_PIECE(IDX, DSTBUF)                                                                  \
-  {                                                                                                  \
-    if ((IDX) == 0) {                                                                                \
-      f_dy = 0; f_dx = 0;                                                                            \
-      if (p.ksize == 3) { f_dy = (tap * 11) >> 5; f_dx = tap - 3 * f_dy; }                           \
-      f_tap_off = (f_dy * p.W + f_dx) * p.cin + ch_base + ch;                                        \
-      f_dst = smem_addr + (unsigned)(((DSTBUF) * STAGE + 8 * wave_u * LDS_ROW) * 4);                 \
-    }                                                                                                \
-    if constexpr ((IDX) < AP) {                                                                      \
-      constexpr int i = (IDX);                                                                       \
-      const int iy = a_iy[i] + f_dy, ix = a_ix[i] + f_dx;                                            \
-      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;                  \
-      const unsigned off = ok ? (unsigned)(a_pix[i] + f_tap_off) * 4u : OOB;                         \
-      UT_DIAG_A(dma16(a_words, f_dst + 32 * i * LDS_ROW * 4, off));                                  \
-    } else if constexpr ((IDX) < AP + BP) {                                                          \
-      constexpr int i = (IDX) - AP;                                                                  \
-      UT_DIAG_B(dma16(b_words, f_dst + (BM + 32 * i) * LDS_ROW * 4, b_off + i * b_row_step));        \
-    }                                                                                                \
-    if ((IDX) == AP + BP - 1) { /* advance to the next chunk */                                      \
-      b_off += BK * 4;                                                                               \
-      ch += BK;                                                                                      \
-      if (ch >= p.cslice) { ch -= p.cslice; ++tap; }                                                 \
-      if (tap >= taps) { tap -= taps; ch_base += p.cslice; }                                         \
-    }                                                                                                \
-  }
-
   // MFMA C layout with the operands as above: lane = pixel (column fr of the 32-pixel fragment), register e =
   // output channel (e&3) + 8*(e>>2) + 4*fh of the 32-channel fragment.  Four consecutive registers are four
   // consecutive channels of one pixel: one 16-byte access in NHWC.
@@ -313,34 +288,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     UT_MFMA_STEP(SET, x) UT_MFMA_STEP(SET, y) UT_MFMA_STEP(SET, z) UT_MFMA_STEP(SET, w)              \
   }
 #define UT_PIN() __builtin_amdgcn_sched_barrier(0)
-#define UT_MFMA_Q(SET, Q)                                                                            \
-  {                                                                                                  \
-    constexpr int i = (Q) / NI, j = (Q) % NI;                                                        \
-    if constexpr ((Q) < MI * NI) {                                                                   \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[j].x, af##SET[i].x, acc[i][j], 0, 0, 0); \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[j].y, af##SET[i].y, acc[i][j], 0, 0, 0); \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[j].z, af##SET[i].z, acc[i][j], 0, 0, 0); \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[j].w, af##SET[i].w, acc[i][j], 0, 0, 0); \
-    }                                                                                                \
-  }
-  // group G of a chunk with up to 4 MFMA quads; piece (G*MI*NI + q) goes in front of quad q
-#define UT_GROUP_FINE(SET, G, DSTBUF)                                                                \
-  {                                                                                                  \
-    UT_FETCH_PIECE((G) * MI * NI + 0, DSTBUF); UT_PIN(); UT_MFMA_Q(SET, 0); UT_PIN();                \
-    if constexpr (MI * NI > 1) { UT_FETCH_PIECE((G) * MI * NI + 1, DSTBUF); UT_PIN(); UT_MFMA_Q(SET, 1); UT_PIN(); } \
-    if constexpr (MI * NI > 2) { UT_FETCH_PIECE((G) * MI * NI + 2, DSTBUF); UT_PIN(); UT_MFMA_Q(SET, 2); UT_PIN(); } \
-    if constexpr (MI * NI > 3) { UT_FETCH_PIECE((G) * MI * NI + 3, DSTBUF); UT_PIN(); UT_MFMA_Q(SET, 3); UT_PIN(); } \
-  }
-#define UT_CHUNK_FINE(buf)                                                                           \
-  {                                                                                                  \
-    static_assert(3 * MI * NI >= AP + BP && MI * NI <= 4, "pieces must fit the MFMA quads in front of the barrier"); \
-    UT_READ(Y, buf, 1); UT_PIN(); UT_GROUP_FINE(X, 0, (buf) ^ 1);                                    \
-    UT_READ(X, buf, 2); UT_PIN(); UT_GROUP_FINE(Y, 1, (buf) ^ 1);                                    \
-    UT_READ(Y, buf, 3); UT_PIN(); UT_GROUP_FINE(X, 2, (buf) ^ 1);                                    \
-    UT_MAYBE_STAGE((buf) ^ 1);                                                                       \
-    UT_BARRIER();                                                                                    \
-    UT_READ(X, (buf) ^ 1, 0); UT_PIN(); UT_MFMA(Y); UT_PIN();                                        \
-  }
 
   // One chunk, software pipelined against LDS latency and the barrier.  On entry set X holds the q=0
   // fragments of this chunk (read under the previous chunk's last MFMA group).  The reads of group q+1 are
@@ -408,13 +355,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     // steady state: fetch chunk c+1 (loads stay in flight under the MFMAs), compute chunk c
     for (int c = 0; c + 1 < n_chunks; ++c) {
 #ifndef UT_DIAG_NO_FETCH    /* timing-only ablations for tools/diag (results are wrong with any of them) */
-#if defined(UT_FINE_FETCH)
-      if constexpr (DMA && 3 * MI * NI >= AP + BP && MI * NI == 4) {
-        UT_CHUNK_FINE(buf);
-      } else {
-        UT_CHUNK(buf, UT_FETCH_PART(0, buf ^ 1), UT_FETCH_PART(1, buf ^ 1), UT_FETCH_PART(2, buf ^ 1));
-      }
-#elif defined(UT_BURST_FETCH)
+#ifdef UT_BURST_FETCH
       UT_FETCH(buf ^ 1);
       UT_CHUNK(buf, , , );
 #else
@@ -518,10 +459,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
 #undef UT_MFMA
 #undef UT_MFMA_STEP
 #undef UT_PIN
-#undef UT_MFMA_Q
-#undef UT_GROUP_FINE
-#undef UT_CHUNK_FINE
-#undef UT_FETCH_PIECE
 #undef UT_BARRIER
 #undef UT_MAYBE_STAGE
 }
@@ -550,9 +487,6 @@ static hipError_t launch_cfg(const ConvLaunch& c, hipStream_t s) {
   // even spacing between ranks is one chunk's MFMA time = (MI*NI) x 16 MFMAs x 64 cycles = (MI*NI) x 2 units
   ConvLaunch cl = c;
   if (c.stagger < 0) cl.stagger = grid > c.num_cu ? (BM / WR / 32) * (BN / WC / 32) * 2 : 0;
-  // stagger -2: offset co-resident workgroups by a whole tile's MFMA time / resident count, so that the per-tile
-  // epilogue + prologue of one workgroup falls into the steady state of the others instead of coinciding
-  if (c.stagger == -2 && grid > c.num_cu) cl.stagger *= c.k_pad / BK;
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, DMA>), dim3(grid), dim3(256), lds, s, cl, tiles_n, n_tiles);
   return hipGetLastError();
 }

@@ -23,8 +23,7 @@ flops = 2.0 * n_img * hw * hw * cout * k_total
 variants = [("baseline", []), ("no_A_loads", ["-DUT_DIAG_NO_A"]), ("no_B_loads", ["-DUT_DIAG_NO_B"]),
             ("no_A_no_B_loads(addr math only)", ["-DUT_DIAG_NO_A", "-DUT_DIAG_NO_B"]), ("no_fetch", ["-DUT_DIAG_NO_FETCH"]), ("no_fetch+no_stage", ["-DUT_DIAG_NO_FETCH", "-DUT_DIAG_NO_STAGE"]),
             ("no_barrier", ["-DUT_DIAG_NO_BARRIER"]),
-            ("no_fetch+no_stage+no_barrier", ["-DUT_DIAG_NO_FETCH", "-DUT_DIAG_NO_STAGE", "-DUT_DIAG_NO_BARRIER"]),
-            ("fine_fetch", ["-DUT_FINE_FETCH"]), ("fine_fetch+no_barrier", ["-DUT_FINE_FETCH", "-DUT_DIAG_NO_BARRIER"])]
+            ("no_fetch+no_stage+no_barrier", ["-DUT_DIAG_NO_FETCH", "-DUT_DIAG_NO_STAGE", "-DUT_DIAG_NO_BARRIER"])]
 only = os.environ.get("UT_ABLATE_ONLY")
 if only:
     variants = [v for v in variants if v[0] in only.split(",")]
