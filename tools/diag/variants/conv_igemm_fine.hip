@@ -8,27 +8,22 @@
 // channel) - see ut_kernels.h.  Activations are NHWC so a k-run of 4 channels is one 16-byte load;
 // weights are pre-packed [cout_pad][k_pad] (k contiguous) with BatchNorm folded in.
 //
-// A workgroup (4 waves, 256 threads) computes BM x BN output tiles and walks K in chunks of 32.  Operands go
-// global -> LDS directly (buffer_load_dwordx4 ... lds, 1 KB per wave-instruction): the im2col gather for the
-// pixels, plain rows for the weights; out-of-image taps and rows beyond M get an out-of-range buffer offset and
-// arrive as zeros, so the load path has no branches.  LDS rows are 128 B, unpadded, their 16-byte chunks
-// XOR-swizzled by (row >> 1) & 7 on the SOURCE side (which chunk a lane fetches), which makes the ds_read_b128
-// fragment reads conflict free under gfx950's 16-lane read groups.  Two stages, one barrier per chunk.  (The
-// register-staged variant DMA = false, rows padded to 36 floats, is kept for comparison: UT_CONV_DMA.)
+// A workgroup (4 waves, 256 threads) computes BM x BN output tiles and walks K in chunks of 32:
+//   buffer loads (im2col gather; out-of-image taps get an out-of-range offset and read as 0, so the load
+//   path has no branches) -> registers -> LDS (double buffered, rows padded to 36 floats so that the
+//   ds_read_b128 fragment reads are bank-conflict free) -> 4 MFMA 32x32x2 per fragment pair.
 // Lane l of a wave holds row (l&31) of the fragment and k-half (l>>5); the 4 floats of a b128 read feed
 // 4 consecutive MFMAs (the k order inside the 8-run is permuted identically for A and B).
 //
-// Workgroups are PERSISTENT: a grid of (CUs x resident workgroups) takes tiles from a device-wide queue (first
-// round: static XCD-contiguous slots; afterwards one atomic ticket per workgroup per tile, requested a tile
-// ahead by wave 0 and handed to the other waves through an LDS word), and the first chunk, bias and residual of
-// the next tile are fetched under the last chunk of the current one.  A 64-cycle MFMA makes operand traffic
-// cheap; what costs throughput is every cycle the matrix pipe waits for a tile prologue (index math,
-// first-touch latency, residual fetch) or for a store-bound epilogue.
+// Workgroups are PERSISTENT: a grid of (CUs x resident blocks) walks the tile list, and the first chunk,
+// bias and residual of the next tile are fetched under the last chunk of the current one.  A 64-cycle MFMA
+// makes operand traffic cheap; what costs throughput is every cycle the matrix pipe waits for a tile
+// prologue (index math, first-touch HBM latency, residual fetch), and co-resident workgroups with equal
+// work fall into lockstep so that their prologues coincide.  With the prologue hidden the per-tile bubble
+// is the accumulator drain + store issue only.
 // Accumulators start at bias (+ residual); epilogue = (ReLU) + store.  The weights are the MFMA "A" operand
 // and the pixels the "B" operand, so in the C layout (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
 // a lane owns one pixel and register quads are 4 consecutive channels: 16-byte NHWC loads and stores.
-// Tile shapes: 128x128 (cout > 64), 128x64 (cout <= 64, three workgroups per CU), 64x128 for launches with few
-// tiles (projection and head: 74 k pixels); layer1 (3x3, 32 -> 32) runs in conv_patch.hip instead.
 #include <stdlib.h>
 
 #include "ut_kernels.h"
@@ -91,10 +86,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
   constexpr int LDS_ROW = lds_row<DMA>();
   constexpr int STAGE = (BM + BN) * LDS_ROW;
   constexpr unsigned OOB = 0xFFFFFF00u;
-#ifndef UT_FINE_MASK
-#define UT_FINE_MASK 6          /* bit per MI*NI value (1, 2, 4): the 128x128 and 128x64 shapes */
-#endif
-  constexpr bool FINE = ((UT_FINE_MASK >> (MI * NI == 4 ? 2 : MI * NI == 2 ? 1 : 0)) & 1) && AP + BP <= 12;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -270,25 +261,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
       }                                                                                              \
     }                                                                                                \
   }
-  // the same requests for one accumulator (i, j) = (Q / NI, Q % NI) only: slipped between the MFMA steps of a
-  // tile's last chunk.  Safe for TILE >= n_tiles (no next tile): rows are beyond M, so every offset is out of range.
-#define UT_INIT_LOAD_PART(TILE, Q)                                                                   \
-  if constexpr ((Q) < MI * NI) {                                                                     \
-    constexpr int i = (Q) / NI, j = (Q) % NI;                                                        \
-    const int tm_ = (TILE) / tiles_n, tn_ = (TILE) - tm_ * tiles_n;                                  \
-    if constexpr (i == 0) {                                                                          \
-      _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4)                                               \
-        bias_raw[j][g4] = *reinterpret_cast<const float4*>(                                          \
-            p.bias + tn_ * BN + wn * (NI * 32) + j * 32 + 8 * g4 + 4 * fh);                          \
-    }                                                                                                \
-    const int m = tm_ * BM + wm * (MI * 32) + i * 32 + fr;                                           \
-    const bool m_ok = m < M;                                                                         \
-    _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4) {                                               \
-      const int n = tn_ * BN + wn * (NI * 32) + j * 32 + 8 * g4 + 4 * fh;                            \
-      const unsigned off = (m_ok && n < p.cout_store) ? (unsigned)(m * p.cout_store + n) * 4u : OOB; \
-      res_raw[i][j][g4] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0);                  \
-    }                                                                                                \
-  }
   /* NB: __builtin_bit_cast on a vector ELEMENT (r.y) miscompiles to a splat of r.x (ROCm 7.2): __uint_as_float */
 #define UT_INIT_COMBINE()                                                                            \
   _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                     \
@@ -341,30 +313,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     UT_MFMA_STEP(SET, x) UT_MFMA_STEP(SET, y) UT_MFMA_STEP(SET, z) UT_MFMA_STEP(SET, w)              \
   }
 #define UT_PIN() __builtin_amdgcn_sched_barrier(0)
-
-  // Fine interleave: one LDS-DMA piece in front of every MFMA step (a step = one k of all MI*NI accumulators),
-  // instead of three bursts per chunk: a piece issued among bare MFMAs costs the issuing wave ~60 cycles, one
-  // issued next to other pieces and the fragment reads 100-185 (MI355X_MICROARCH.md, LDS-DMA piece issue cost).
-#if defined(UT_PRIO_VARIANT) && UT_PRIO_VARIANT == 1      /* diag: loader stretch at raised priority */
-#define UT_PRIO_LOAD() __builtin_amdgcn_s_setprio(1)
-#define UT_PRIO_MFMA() __builtin_amdgcn_s_setprio(0)
-#elif defined(UT_PRIO_VARIANT) && UT_PRIO_VARIANT == 2    /* diag: MFMA stretch at raised priority */
-#define UT_PRIO_LOAD() __builtin_amdgcn_s_setprio(0)
-#define UT_PRIO_MFMA() __builtin_amdgcn_s_setprio(1)
-#else
-#define UT_PRIO_LOAD()
-#define UT_PRIO_MFMA()
-#endif
-#define UT_STEP_FINE(SET, C, IDX, DSTBUF)                                                            \
-  { UT_PRIO_LOAD(); UT_FETCH_PIECE(IDX, DSTBUF); UT_PRIO_MFMA(); UT_PIN(); UT_MFMA_STEP(SET, C) UT_PIN(); }
+#define UT_MFMA_Q(SET, Q)                                                                            \
+  {                                                                                                  \
+    constexpr int i = (Q) / NI, j = (Q) % NI;                                                        \
+    if constexpr ((Q) < MI * NI) {                                                                   \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[j].x, af##SET[i].x, acc[i][j], 0, 0, 0); \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[j].y, af##SET[i].y, acc[i][j], 0, 0, 0); \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[j].z, af##SET[i].z, acc[i][j], 0, 0, 0); \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[j].w, af##SET[i].w, acc[i][j], 0, 0, 0); \
+    }                                                                                                \
+  }
+  // group G of a chunk with up to 4 MFMA quads; piece (G*MI*NI + q) goes in front of quad q
 #define UT_GROUP_FINE(SET, G, DSTBUF)                                                                \
   {                                                                                                  \
-    UT_STEP_FINE(SET, x, 4 * (G) + 0, DSTBUF) UT_STEP_FINE(SET, y, 4 * (G) + 1, DSTBUF)              \
-    UT_STEP_FINE(SET, z, 4 * (G) + 2, DSTBUF) UT_STEP_FINE(SET, w, 4 * (G) + 3, DSTBUF)              \
+    UT_FETCH_PIECE((G) * MI * NI + 0, DSTBUF); UT_PIN(); UT_MFMA_Q(SET, 0); UT_PIN();                \
+    if constexpr (MI * NI > 1) { UT_FETCH_PIECE((G) * MI * NI + 1, DSTBUF); UT_PIN(); UT_MFMA_Q(SET, 1); UT_PIN(); } \
+    if constexpr (MI * NI > 2) { UT_FETCH_PIECE((G) * MI * NI + 2, DSTBUF); UT_PIN(); UT_MFMA_Q(SET, 2); UT_PIN(); } \
+    if constexpr (MI * NI > 3) { UT_FETCH_PIECE((G) * MI * NI + 3, DSTBUF); UT_PIN(); UT_MFMA_Q(SET, 3); UT_PIN(); } \
   }
 #define UT_CHUNK_FINE(buf)                                                                           \
   {                                                                                                  \
-    static_assert(12 >= AP + BP, "pieces must fit the MFMA steps in front of the barrier");          \
+    static_assert(3 * MI * NI >= AP + BP && MI * NI <= 4, "pieces must fit the MFMA quads in front of the barrier"); \
     UT_READ(Y, buf, 1); UT_PIN(); UT_GROUP_FINE(X, 0, (buf) ^ 1);                                    \
     UT_READ(X, buf, 2); UT_PIN(); UT_GROUP_FINE(Y, 1, (buf) ^ 1);                                    \
     UT_READ(Y, buf, 3); UT_PIN(); UT_GROUP_FINE(X, 2, (buf) ^ 1);                                    \
@@ -372,20 +341,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     UT_BARRIER();                                                                                    \
     UT_READ(X, (buf) ^ 1, 0); UT_PIN(); UT_MFMA(Y); UT_PIN();                                        \
   }
-  // last chunk of a tile: the first chunk of the NEXT tile is fetched the same way, and its bias/residual requests
-  // ride on the piece-free steps of the third group
-#define UT_STEP_INIT(SET, C, Q, TILE) { UT_INIT_LOAD_PART(TILE, Q); UT_PIN(); UT_MFMA_STEP(SET, C) UT_PIN(); }
-#define UT_CHUNK_FINE_LAST(buf, TILE)                                                                \
-  {                                                                                                  \
-    static_assert(8 >= AP + BP, "the third group carries the accumulator requests");                 \
-    UT_READ(Y, buf, 1); UT_PIN(); UT_GROUP_FINE(X, 0, (buf) ^ 1);                                    \
-    UT_READ(X, buf, 2); UT_PIN(); UT_GROUP_FINE(Y, 1, (buf) ^ 1);                                    \
-    UT_READ(Y, buf, 3); UT_PIN();                                                                    \
-    UT_STEP_INIT(X, x, 0, TILE) UT_STEP_INIT(X, y, 1, TILE) UT_STEP_INIT(X, z, 2, TILE) UT_STEP_INIT(X, w, 3, TILE) \
-    UT_MAYBE_STAGE((buf) ^ 1);                                                                       \
-    UT_BARRIER();                                                                                    \
-    UT_READ(X, (buf) ^ 1, 0); UT_PIN(); UT_MFMA(Y); UT_PIN();                                        \
-  }
+
   // One chunk, software pipelined against LDS latency and the barrier.  On entry set X holds the q=0
   // fragments of this chunk (read under the previous chunk's last MFMA group).  The reads of group q+1 are
   // issued before the MFMAs of group q; the next chunk is staged and the barrier passed BEFORE the last
@@ -452,15 +408,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     // steady state: fetch chunk c+1 (loads stay in flight under the MFMAs), compute chunk c
     for (int c = 0; c + 1 < n_chunks; ++c) {
 #ifndef UT_DIAG_NO_FETCH    /* timing-only ablations for tools/diag (results are wrong with any of them) */
-#ifdef UT_BURST_FETCH
-      UT_FETCH(buf ^ 1);
-      UT_CHUNK(buf, , , );
-#else
-      if constexpr (DMA && FINE) {
+#if defined(UT_FINE_FETCH)
+      if constexpr (DMA && 3 * MI * NI >= AP + BP && MI * NI == 4) {
         UT_CHUNK_FINE(buf);
       } else {
         UT_CHUNK(buf, UT_FETCH_PART(0, buf ^ 1), UT_FETCH_PART(1, buf ^ 1), UT_FETCH_PART(2, buf ^ 1));
       }
+#elif defined(UT_BURST_FETCH)
+      UT_FETCH(buf ^ 1);
+      UT_CHUNK(buf, , , );
+#else
+      UT_CHUNK(buf, UT_FETCH_PART(0, buf ^ 1), UT_FETCH_PART(1, buf ^ 1), UT_FETCH_PART(2, buf ^ 1));
 #endif
 #else
       UT_CHUNK(buf, , , );
@@ -487,21 +445,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(next_v) : "v"(slot_addr) : "memory");
     const int next = __builtin_amdgcn_readfirstlane(next_v);
     const bool has_next = next < n_tiles;
-#ifndef UT_LAST_BURST
-    if constexpr (DMA && FINE && AP + BP <= 8) {
-      // no branch: without a next tile (next >= n_tiles) every row is beyond M and the requests return zeros
+    if (has_next) {
       UT_SETUP(next);
-      UT_CHUNK_FINE_LAST(buf, next);
-    } else
-#endif
-    {
-      if (has_next) {
-        UT_SETUP(next);
-        UT_FETCH(buf ^ 1);
-        UT_INIT_LOAD(next);
-      }
-      UT_CHUNK(buf, , , );
+      UT_FETCH(buf ^ 1);
+      UT_INIT_LOAD(next);
     }
+    UT_CHUNK(buf, , , );
     buf ^= 1;
 #ifdef UT_STAMPS
     if (tiles_done == 0) UT_STAMP(3);
@@ -569,12 +518,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
 #undef UT_MFMA
 #undef UT_MFMA_STEP
 #undef UT_PIN
-#undef UT_STEP_FINE
-#undef UT_STEP_INIT
-#undef UT_CHUNK_FINE_LAST
-#undef UT_INIT_LOAD_PART
-#undef UT_PRIO_LOAD
-#undef UT_PRIO_MFMA
+#undef UT_MFMA_Q
 #undef UT_GROUP_FINE
 #undef UT_CHUNK_FINE
 #undef UT_FETCH_PIECE
@@ -606,6 +550,9 @@ static hipError_t launch_cfg(const ConvLaunch& c, hipStream_t s) {
   // even spacing between ranks is one chunk's MFMA time = (MI*NI) x 16 MFMAs x 64 cycles = (MI*NI) x 2 units
   ConvLaunch cl = c;
   if (c.stagger < 0) cl.stagger = grid > c.num_cu ? (BM / WR / 32) * (BN / WC / 32) * 2 : 0;
+  // stagger -2: offset co-resident workgroups by a whole tile's MFMA time / resident count, so that the per-tile
+  // epilogue + prologue of one workgroup falls into the steady state of the others instead of coinciding
+  if (c.stagger == -2 && grid > c.num_cu) cl.stagger *= c.k_pad / BK;
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, DMA>), dim3(grid), dim3(256), lds, s, cl, tiles_n, n_tiles);
   return hipGetLastError();
 }
