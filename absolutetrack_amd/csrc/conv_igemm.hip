@@ -345,29 +345,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
   // Fine interleave: one LDS-DMA piece in front of every MFMA step (a step = one k of all MI*NI accumulators),
   // instead of three bursts per chunk: a piece issued among bare MFMAs costs the issuing wave ~60 cycles, one
   // issued next to other pieces and the fragment reads 100-185 (MI355X_MICROARCH.md, LDS-DMA piece issue cost).
-#if defined(UT_PRIO_VARIANT) && UT_PRIO_VARIANT == 1      /* diag: loader stretch at raised priority */
-#define UT_PRIO_LOAD() __builtin_amdgcn_s_setprio(1)
-#define UT_PRIO_MFMA() __builtin_amdgcn_s_setprio(0)
-#elif defined(UT_PRIO_VARIANT) && UT_PRIO_VARIANT == 2    /* diag: MFMA stretch at raised priority */
-#define UT_PRIO_LOAD() __builtin_amdgcn_s_setprio(0)
-#define UT_PRIO_MFMA() __builtin_amdgcn_s_setprio(1)
-#else
-#define UT_PRIO_LOAD()
-#define UT_PRIO_MFMA()
-#endif
 #define UT_STEP_FINE(SET, C, IDX, DSTBUF)                                                            \
-  { UT_PRIO_LOAD(); UT_FETCH_PIECE(IDX, DSTBUF); UT_PRIO_MFMA(); UT_PIN(); UT_MFMA_STEP(SET, C) UT_PIN(); }
+  { UT_FETCH_PIECE(IDX, DSTBUF); UT_PIN(); UT_MFMA_STEP(SET, C) UT_PIN(); }
 #define UT_GROUP_FINE(SET, G, DSTBUF)                                                                \
   {                                                                                                  \
     UT_STEP_FINE(SET, x, 4 * (G) + 0, DSTBUF) UT_STEP_FINE(SET, y, 4 * (G) + 1, DSTBUF)              \
     UT_STEP_FINE(SET, z, 4 * (G) + 2, DSTBUF) UT_STEP_FINE(SET, w, 4 * (G) + 3, DSTBUF)              \
   }
+#define UT_GROUP_FINE_R(SET, G, DSTBUF, READ) { READ; UT_PIN(); UT_GROUP_FINE(SET, G, DSTBUF); }
 #define UT_CHUNK_FINE(buf)                                                                           \
   {                                                                                                  \
     static_assert(12 >= AP + BP, "pieces must fit the MFMA steps in front of the barrier");          \
-    UT_READ(Y, buf, 1); UT_PIN(); UT_GROUP_FINE(X, 0, (buf) ^ 1);                                    \
-    UT_READ(X, buf, 2); UT_PIN(); UT_GROUP_FINE(Y, 1, (buf) ^ 1);                                    \
-    UT_READ(Y, buf, 3); UT_PIN(); UT_GROUP_FINE(X, 2, (buf) ^ 1);                                    \
+    UT_GROUP_FINE_R(X, 0, (buf) ^ 1, UT_READ(Y, buf, 1));                                            \
+    UT_GROUP_FINE_R(Y, 1, (buf) ^ 1, UT_READ(X, buf, 2));                                            \
+    UT_GROUP_FINE_R(X, 2, (buf) ^ 1, UT_READ(Y, buf, 3));                                            \
     UT_MAYBE_STAGE((buf) ^ 1);                                                                       \
     UT_BARRIER();                                                                                    \
     UT_READ(X, (buf) ^ 1, 0); UT_PIN(); UT_MFMA(Y); UT_PIN();                                        \
@@ -570,11 +561,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
 #undef UT_MFMA_STEP
 #undef UT_PIN
 #undef UT_STEP_FINE
+#undef UT_GROUP_FINE_R
 #undef UT_STEP_INIT
 #undef UT_CHUNK_FINE_LAST
 #undef UT_INIT_LOAD_PART
-#undef UT_PRIO_LOAD
-#undef UT_PRIO_MFMA
 #undef UT_GROUP_FINE
 #undef UT_CHUNK_FINE
 #undef UT_FETCH_PIECE

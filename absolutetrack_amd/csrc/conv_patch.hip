@@ -198,11 +198,32 @@ __global__ __launch_bounds__(512) void conv3x3_c32_patch_kernel(ConvLaunch p, in
 #else
 #define UTP_STAMP(IDX)
 #endif
+#define UTP_EPILOGUE(M_)                                                                              \
+  {                                                                                                  \
+    const int m_ = (M_);                                                                             \
+    _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4) {                                               \
+      const int n = 8 * g4 + 4 * fh;                                                                 \
+      u32x4 pk;                                                                                      \
+      float v0 = acc[4 * g4], v1 = acc[4 * g4 + 1], v2 = acc[4 * g4 + 2], v3 = acc[4 * g4 + 3];      \
+      if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); } \
+      pk.x = __float_as_uint(v0); pk.y = __float_as_uint(v1); pk.z = __float_as_uint(v2); pk.w = __float_as_uint(v3); \
+      __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, (unsigned)(m_ * C + n) * 4u, 0, 0);         \
+    }                                                                                                \
+  }
+#ifdef UTP_NO_ROTATE
+  const bool late = false;
+#else
+  const bool late = wave >= 4;        // wave is uniform (readfirstlane)
+#endif
+  bool have_prev = false;
+  int prev_m = 0;
   f32x16 ready = init_combine();      // bias + residual of the tile about to be computed
+  f32x16 acc;
   for (;;) {
     UTP_STAMP(0);
     const bool has_next = next < n_tiles;
-    f32x16 acc = ready;
+    if (late && have_prev) { UTP_EPILOGUE(prev_m); }
+    acc = ready;
     // ticket for the tile after next: issued now, consumed before the last tap
     const int ticket = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, q_rsrc, q_off, 0, 0);
     int n_row0 = 0, n_y0 = 0, n_x0 = 0;
@@ -254,19 +275,12 @@ __global__ __launch_bounds__(512) void conv3x3_c32_patch_kernel(ConvLaunch p, in
 #undef UTP_MFMA
 #undef UTP_PIN
     UTP_STAMP(3);
-    // epilogue: (ReLU) + 4 x 16-byte stores per lane
-    {
-      const int m = (c_row0 + c_y0 + ly) * W + c_x0 + lx;
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int n = 8 * g4 + 4 * fh;
-        u32x4 pk;
-        float v0 = acc[4 * g4], v1 = acc[4 * g4 + 1], v2 = acc[4 * g4 + 2], v3 = acc[4 * g4 + 3];
-        if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-        pk.x = __float_as_uint(v0); pk.y = __float_as_uint(v1); pk.z = __float_as_uint(v2); pk.w = __float_as_uint(v3);
-        __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, (unsigned)(m * C + n) * 4u, 0, 0);
-      }
-    }
+    // epilogue: (ReLU) + 4 x 16-byte stores per lane.  Waves 0-3 store right after their MFMAs; waves 4-7 (the
+    // SIMD partners of 0-3: a workgroup's waves w and w+4 share a SIMD) keep the tile in registers and store it at
+    // the top of the NEXT tile instead, so that within a barrier interval one partner stores while the other
+    // still feeds the matrix pipe - partners running the same program otherwise reach their store phase together.
+    if (!late) { UTP_EPILOGUE((c_row0 + c_y0 + ly) * W + c_x0 + lx); }
+    else { prev_m = (c_row0 + c_y0 + ly) * W + c_x0 + lx; have_prev = true; }
     UTP_STAMP(4);
     if (!has_next) break;
     // every wave's pieces of the next patch have landed and everyone is done reading the current one
@@ -282,6 +296,8 @@ __global__ __launch_bounds__(512) void conv3x3_c32_patch_kernel(ConvLaunch p, in
     c_row0 = n_row0; c_y0 = n_y0; c_x0 = n_x0;
     cur ^= 1;
   }
+  if (late && have_prev) { UTP_EPILOGUE(prev_m); }
+#undef UTP_EPILOGUE
 }
 
 bool conv_patch_applicable(const ConvLaunch& c) {
