@@ -81,7 +81,7 @@ __device__ __forceinline__ int fast_div(int n, int d, float inv_d) {
   return q;
 }
 
-template <int BM, int BN, int WR, int WC, bool DMA>
+template <int BM, int BN, int WR, int WC, bool DMA, bool NCHW = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int tiles_n, int n_tiles) {
   static_assert(WR * WC == 4, "4 waves per workgroup");
   constexpr int MI = BM / WR / 32;   // 32x32 accumulator tiles per wave along M
@@ -502,11 +502,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     // quads beyond cout get an out-of-range offset and are dropped): straight-line 16-byte stores, so the
     // compiler counts them exactly instead of draining the memory pipe before the next tile.
     const int m0 = tm * BM, n0 = tn * BN;
+    const float relu_floor = p.relu ? 0.f : -__builtin_huge_valf();
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = m0 + wm * (MI * 32) + i * 32 + fr;
       const bool m_ok = m < M;
-      const int img = p.out_nchw ? fast_div(m_ok ? m : 0, hw, inv_hw) : 0;
+      const int img = NCHW ? fast_div(m_ok ? m : 0, hw, inv_hw) : 0;
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
 #pragma unroll
@@ -516,9 +517,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             v[k] = acc[i][j][4 * g4 + k];
-            if (p.relu) v[k] = fmaxf(v[k], 0.f);
+            v[k] = fmaxf(v[k], relu_floor);   // 0 with ReLU, -inf without: one v_max, no branch
           }
-          if (!p.out_nchw) {
+          if constexpr (!NCHW) {
             const unsigned off = (m_ok && n < p.cout_store) ? (unsigned)(m * p.cout_store + n) * 4u : OOB;
             u32x4 pk;
             pk.x = __float_as_uint(v[0]); pk.y = __float_as_uint(v[1]);
@@ -572,7 +573,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
 #undef UT_MAYBE_STAGE
 }
 
-template <int BM, int BN, int WR, int WC, bool DMA>
+template <int BM, int BN, int WR, int WC, bool DMA, bool NCHW = false>
 static hipError_t launch_cfg(const ConvLaunch& c, hipStream_t s) {
   const int M = c.n_img * c.Ho * c.Wo;
   const int tiles_m = (M + BM - 1) / BM;
@@ -581,7 +582,7 @@ static hipError_t launch_cfg(const ConvLaunch& c, hipStream_t s) {
   const size_t lds = 2 * (size_t)(BM + BN) * lds_row<DMA>() * sizeof(float) + 16;   // + tile-queue slot
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, DMA>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, DMA, NCHW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
@@ -596,7 +597,7 @@ static hipError_t launch_cfg(const ConvLaunch& c, hipStream_t s) {
   // even spacing between ranks is one chunk's MFMA time = (MI*NI) x 16 MFMAs x 64 cycles = (MI*NI) x 2 units
   ConvLaunch cl = c;
   if (c.stagger < 0) cl.stagger = grid > c.num_cu ? (BM / WR / 32) * (BN / WC / 32) * 2 : 0;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, DMA>), dim3(grid), dim3(256), lds, s, cl, tiles_n, n_tiles);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, DMA, NCHW>), dim3(grid), dim3(256), lds, s, cl, tiles_n, n_tiles);
   return hipGetLastError();
 }
 
@@ -612,8 +613,7 @@ hipError_t launch_conv_igemm(const ConvLaunch& c, hipStream_t s) {
   static const int use_patch = [] { const char* e = getenv("UT_CONV_PATCH"); return e ? atoi(e) : 1; }();
   if (use_patch && conv_patch_applicable(c)) return launch_conv_patch(c, s);
   static const int dma = [] { const char* e = getenv("UT_CONV_DMA"); return e ? atoi(e) : 7; }();   // bit per tile config
-  static const int big32 = [] { const char* e = getenv("UT_CONV_BIG32"); return e ? atoi(e) : 0; }();
-  if (c.cout_store <= 32 && big32) return launch_cfg<256, 32, 4, 1, true>(c, s);
+  if (c.out_nchw) return launch_cfg<64, 128, 1, 4, true, true>(c, s);      // projection: the only NCHW output
   if (c.cout_store <= 32) return (dma & 1) ? launch_cfg<128, 32, 4, 1, true>(c, s) : launch_cfg<128, 32, 4, 1, false>(c, s);
   if (c.cout_store <= 64) return (dma & 2) ? launch_cfg<128, 64, 2, 2, true>(c, s) : launch_cfg<128, 64, 2, 2, false>(c, s);
   // few-tile launches (the head: 73,728 pixels = 576 tiles of 128 rows on 512 resident slots, i.e. two rounds the
