@@ -2,7 +2,7 @@
 """Diagnostic (not part of the product): interleaved A/B timing of conv_igemm variants on one layer shape.
 Every variant is built into its own scratch library (source file + flags), all are loaded, and the launches are
 timed in interleaved rounds so that clock / thermal drift hits all variants alike; reports median and min.
-    python tools/diag/conv_ab.py <cin> <cout> <hw> <n_img> name=src.hip[:flag,flag] ...
+    python tools/diag/conv_ab.py <cin> <cout> <hw> <n_img> name=src.hip[:flag,flag,env:KEY=VAL] ...
 e.g. python tools/diag/conv_ab.py 128 128 12 4096 base=absolutetrack_amd/csrc/conv_igemm.hip fine=/tmp/x.hip:-DUT_FINE_FETCH"""
 import ctypes
 import os
@@ -27,7 +27,8 @@ libs = []
 for spec in sys.argv[5:]:
     name, rest = spec.split("=", 1)
     src, _, fl = rest.partition(":")
-    flags = [f for f in fl.split(",") if f]
+    flags = [f for f in fl.split(",") if f and not f.startswith("env:")]
+    envs = [f[4:].split("=", 1) for f in fl.split(",") if f.startswith("env:")]   # read by the library at its first call
     so = f"/tmp/libconvab_{name}.so"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w", *flags,
                            "-o", so, os.path.join(ROOT, src) if not os.path.isabs(src) else src,
@@ -35,7 +36,7 @@ for spec in sys.argv[5:]:
                            "-I", CSRC])
     lib = ctypes.CDLL(so)
     lib.conv_diag.restype = ctypes.c_int
-    libs.append((name, lib))
+    libs.append((name, lib, envs))
 
 
 def run(lib):
@@ -44,18 +45,22 @@ def run(lib):
 
 
 ref = None
-for name, lib in libs:
+for name, lib, envs in libs:
+    for k, v in envs:
+        os.environ[k] = v
     for _ in range(2):
         assert run(lib) == 0
     torch.cuda.synchronize()
+    for k, _v in envs:
+        os.environ.pop(k, None)
     o = out.clone()
     if ref is None:
         ref = o
     else:
         print(f"{name}: max |out - {libs[0][0]}| = {float((o - ref).abs().max()):.3e}")
-times = {name: [] for name, _ in libs}
+times = {name: [] for name, _l, _e in libs}
 for rnd in range(10):
-    for name, lib in libs:
+    for name, lib, _e in libs:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(4):
@@ -63,7 +68,7 @@ for rnd in range(10):
         e1.record()
         torch.cuda.synchronize()
         times[name].append(e0.elapsed_time(e1) / 4)
-for name, _ in libs:
+for name, _l, _e in libs:
     t = times[name]
     med, mn = statistics.median(t), min(t)
     print(f"{name:24s} median {med*1e3:8.1f} us ({flops/med/1e9:6.1f} TF)   min {mn*1e3:8.1f} us ({flops/mn/1e9:6.1f} TF)")
