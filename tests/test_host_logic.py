@@ -255,3 +255,18 @@ def test_torch_data_time_step_batching_matches_oracle():
         td.unpack_batched_data(mi, "stereo")
     with pytest.raises(ValueError):
         rt.unpack_batched_data(img, k, x, hand, axes, rest, "stereo")
+
+
+def test_boundary_header_is_plain_c_and_callable_from_c(tmp_path):
+    """include/umetrack_hip.h compiles as C99 and the library's entry points work through C function pointers
+    (argument validation only - no GPU call)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None or not os.path.exists(_native.LIB_PATH):
+        pytest.skip("needs gcc and the built library")
+    exe = str(tmp_path / "abi_check")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "abi_check.c"), "-o", exe, "-ldl"])
+    out = subprocess.run([exe, _native.LIB_PATH], capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stderr)
+    assert int(out.stdout.strip()) == sum(int(np.prod(s)) for _k, s, _kind in arch.state_dict_spec())
