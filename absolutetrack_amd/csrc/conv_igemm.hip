@@ -81,7 +81,7 @@ __device__ __forceinline__ int fast_div(int n, int d, float inv_d) {
   return q;
 }
 
-template <int BM, int BN, int WR, int WC, bool DMA, bool NCHW = false>
+template <int BM, int BN, int WR, int WC, bool DMA, bool NCHW = false, bool C32 = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int tiles_n, int n_tiles) {
   static_assert(WR * WC == 4, "4 waves per workgroup");
   constexpr int MI = BM / WR / 32;   // 32x32 accumulator tiles per wave along M
@@ -175,11 +175,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
       const int oy = fast_div(rem, p.Wo, inv_wo), ox = rem - oy * p.Wo;                              \
       a_iy[i] = ok ? oy * p.stride - p.pad : -100000; /* rows beyond M never pass the bounds test */ \
       a_ix[i] = ox * p.stride - p.pad;                                                               \
-      a_pix[i] = ((img * p.H + a_iy[i]) * p.W + a_ix[i]) * p.cin;                                    \
+      a_pix[i] = ((img * p.H + a_iy[i]) * p.W + a_ix[i]) * p.cin + (C32 ? 4 * gk : 0);               \
     }                                                                                                \
     b_off = (unsigned)(((tn_ * BN + r0) * p.k_pad + 4 * gk) * 4);                                    \
     /* (slice, tap, channel in slice) of this thread's 4-float group: cslice >= 32 */                \
-    tap = 0; ch = 4 * gk; ch_base = 0;                                                               \
+    /* C32 (channel slice == chunk width): the thread's 4-float group is folded into a_pix, so (tap, ch,    \
+       ch_base) advance identically in every lane and the compiler keeps them - and the tap offset - scalar */ \
+    tap = 0; ch = C32 ? 0 : 4 * gk; ch_base = 0;                                                     \
   }
 
   // The AP+BP 16-byte loads of a chunk are issued in three parts, one in front of each of the first three
@@ -573,7 +575,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
 #undef UT_MAYBE_STAGE
 }
 
-template <int BM, int BN, int WR, int WC, bool DMA, bool NCHW = false>
+template <int BM, int BN, int WR, int WC, bool DMA, bool NCHW = false, bool C32 = false>
 static hipError_t launch_cfg(const ConvLaunch& c, hipStream_t s) {
   const int M = c.n_img * c.Ho * c.Wo;
   const int tiles_m = (M + BM - 1) / BM;
@@ -582,7 +584,7 @@ static hipError_t launch_cfg(const ConvLaunch& c, hipStream_t s) {
   const size_t lds = 2 * (size_t)(BM + BN) * lds_row<DMA>() * sizeof(float) + 16;   // + tile-queue slot
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, DMA, NCHW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, DMA, NCHW, C32>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
@@ -597,7 +599,7 @@ static hipError_t launch_cfg(const ConvLaunch& c, hipStream_t s) {
   // even spacing between ranks is one chunk's MFMA time = (MI*NI) x 16 MFMAs x 64 cycles = (MI*NI) x 2 units
   ConvLaunch cl = c;
   if (c.stagger < 0) cl.stagger = grid > c.num_cu ? (BM / WR / 32) * (BN / WC / 32) * 2 : 0;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, DMA, NCHW>), dim3(grid), dim3(256), lds, s, cl, tiles_n, n_tiles);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, DMA, NCHW, C32>), dim3(grid), dim3(256), lds, s, cl, tiles_n, n_tiles);
   return hipGetLastError();
 }
 
@@ -615,6 +617,9 @@ hipError_t launch_conv_igemm(const ConvLaunch& c, hipStream_t s) {
   static const int dma = [] { const char* e = getenv("UT_CONV_DMA"); return e ? atoi(e) : 7; }();   // bit per tile config
   if (c.out_nchw) return launch_cfg<64, 128, 1, 4, true, true>(c, s);      // projection: the only NCHW output
   if (c.cout_store <= 32) return (dma & 1) ? launch_cfg<128, 32, 4, 1, true>(c, s) : launch_cfg<128, 32, 4, 1, false>(c, s);
+  static const int c32 = [] { const char* e = getenv("UT_CONV_C32"); return e ? atoi(e) : 1; }();
+  const bool u = c32 && c.cslice == BK;     // backbone convolutions: scalar tap bookkeeping
+  if (c.cout_store <= 64 && (dma & 2) && u) return launch_cfg<128, 64, 2, 2, true, false, true>(c, s);
   if (c.cout_store <= 64) return (dma & 2) ? launch_cfg<128, 64, 2, 2, true>(c, s) : launch_cfg<128, 64, 2, 2, false>(c, s);
   // few-tile launches (the head: 73,728 pixels = 576 tiles of 128 rows on 512 resident slots, i.e. two rounds the
   // second of which is 12 % full): half-height tiles, three workgroups per CU
@@ -624,6 +629,7 @@ hipError_t launch_conv_igemm(const ConvLaunch& c, hipStream_t s) {
     const long tiles128 = ((M + 127) / 128) * ((c.cout_store + 127) / 128);
     if (small_m > 0 && tiles128 <= (long)small_m * c.num_cu) return launch_cfg<64, 128, 1, 4, true>(c, s);
   }
+  if ((dma & 4) && u) return launch_cfg<128, 128, 2, 2, true, false, true>(c, s);
   return (dma & 4) ? launch_cfg<128, 128, 2, 2, true>(c, s) : launch_cfg<128, 128, 2, 2, false>(c, s);
 }
 
