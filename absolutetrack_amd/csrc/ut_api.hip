@@ -312,8 +312,8 @@ int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, fl
   c.tile_counter = h->counters + h->counter_next++;
   ProfEvent pe{};
   if (h->profiling) {
-    HIPCHK(h, hipEventCreate(&pe.a));
-    HIPCHK(h, hipEventCreate(&pe.b));
+    HIPCHK(h, hipEventCreateWithFlags(&pe.a, hipEventDisableSystemFence));   // timing only: no system-scope flush per kernel
+    HIPCHK(h, hipEventCreateWithFlags(&pe.b, hipEventDisableSystemFence));
     pe.flops = cw.flops_per_pixel * (double)n_img * c.Ho * c.Wo;
     HIPCHK(h, hipEventRecord(pe.a, s));
   }
