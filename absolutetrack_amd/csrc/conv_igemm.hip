@@ -27,6 +27,9 @@
 // Accumulators start at bias (+ residual); epilogue = (ReLU) + store.  The weights are the MFMA "A" operand
 // and the pixels the "B" operand, so in the C layout (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
 // a lane owns one pixel and register quads are 4 consecutive channels: 16-byte NHWC loads and stores.
+// When the channel slice of the k order equals the chunk width (cin % 32 == 0: every backbone convolution) the
+// C32 instantiation folds the thread's 16-byte k-group into the row offsets, which makes the (slice, tap)
+// bookkeeping of the chunk loop wave-uniform: it runs on the scalar unit and the loop body has no branch.
 // Tile shapes: 128x128 (cout > 64), 128x64 (cout <= 64, three workgroups per CU), 64x128 for launches with few
 // tiles (projection and head: 74 k pixels); layer1 (3x3, 32 -> 32) runs in conv_patch.hip instead.
 #include <stdlib.h>
