@@ -8,6 +8,7 @@ from absolutetrack_amd import _native, arch, pipeline, synth
 from oracle import checks, ref_camera, ref_fk, ref_model
 
 pytestmark = pytest.mark.gpu
+ROOT_DIR = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
 DEV = "cuda:0"
 
 
@@ -245,3 +246,27 @@ def test_batches_beyond_one_pass(engine):
     engine.set_backbone_chunk(7281)
     assert torch.equal(engine.backbone(crops[:7300]), full[:7300])
     engine.set_backbone_chunk(0)
+
+
+def test_independent_processes_share_the_gpu():
+    """The reference runs one model per Pool worker (run_eval_known_skeleton.py:117-119): independent processes,
+    each with its own handle, must be able to use one GPU at the same time and get the single-process result."""
+    import subprocess
+    import sys
+    code = ("import sys, torch; sys.path.insert(0, %r);"
+            "from absolutetrack_amd import _native, pipeline, synth;"
+            "lab = pipeline.load_labels(); hm = pipeline.hand_model_from_labels(lab);"
+            "eng = _native.HipEngine(synth.synthetic_state_dict(0), 'cuda:0');"
+            "plan = {k: v.cpu().numpy() for k, v in pipeline.crop_plan_on_device(lab, hm, range(6), 'cuda:0').items()};"
+            "src = torch.from_numpy(synth.synthetic_frames(6, seed=4).reshape(-1, 480, 636));"
+            "hot = pipeline.HotPath(eng, hm);"
+            "out = [hot.step(pipeline.make_batch(plan, src, 'cuda:0')).double().sum().item() for _ in range(20)];"
+            "assert len(set(out)) == 1; print('SUM', repr(out[0]))") % ROOT_DIR
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for _ in range(3)]
+    sums = []
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, se[-2000:]
+        sums.append([ln for ln in so.splitlines() if ln.startswith("SUM")][0])
+    assert len(set(sums)) == 1, sums
