@@ -3,11 +3,11 @@
 //
 // In the generic implicit GEMM (conv_igemm.hip) every one of the 9 taps re-stages the same pixels through
 // LDS: with only 32 output channels that is 6.5 MAC per staged byte and the global->LDS path (not the MFMA
-// pipe, not latency) is what bounds it at ~60 % of the fp32-MFMA rate.  Here one workgroup (8 waves, one
-// per CU) owns a 16x16-pixel output tile: the 18x18x32 input patch is brought into LDS ONCE by LDS-DMA
+// pipe, not latency) is what bounds it at ~60 % of the fp32-MFMA rate.  Here one workgroup (12 waves, one
+// per CU) owns a 16x24-pixel output tile: the 18x26x32 input patch is brought into LDS ONCE by LDS-DMA
 // (double buffered: the next tile's patch streams in under the current tile's MFMAs), all 9x32x32 weights stay
 // resident in LDS for the life of the (persistent) workgroup, and the 9 taps read shifted windows of the patch.
-// Global->LDS traffic drops from 180 KB to 41 KB per 256 output pixels; there is no barrier inside a tile's
+// Global->LDS traffic drops from 270 KB to 60 KB per 384 output pixels; there is no barrier inside a tile's
 // 144-MFMA stream, one per tile.
 //
 // MFMA operand roles as in conv_igemm.hip: weights = "A" (rows = output channel), pixels = "B" (columns), so a
@@ -23,10 +23,17 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) float lds_f32p;
 
 namespace {
-constexpr int T = 16;                       // output tile is T x T pixels
-constexpr int PW = T + 2;                   // patch width / height
-constexpr int PPIX = PW * PW;               // 324 patch pixels
-constexpr int PROWS = (PPIX + 7) / 8 * 8;   // 328: DMA pieces cover whole 8-row groups
+#ifdef UTP_NARROW                            /* diag: the earlier 16 x 16 tile, 8 waves = two per SIMD */
+constexpr int TY = 16, TX = 16, NW = 8;
+#else
+constexpr int TY = 16, TX = 24, NW = 12;    // output tile is TY x TX pixels, one 32-pixel block per wave: 12 waves,
+                                            // three per SIMD (+3.7 % over two), 157.7 KB of the CU's 160 KB LDS
+#endif
+static_assert(TY * TX == 32 * NW, "one 32-pixel block per wave");
+constexpr int PW = TX + 2, PH = TY + 2;     // patch width / height
+constexpr int PPIX = PW * PH;               // 324 (468) patch pixels
+constexpr int PROWS = (PPIX + 7) / 8 * 8;   // 328 (472): DMA pieces cover whole 8-row groups
+constexpr int PDIV = (65536 + PW - 1) / PW; // pidx / PW == (pidx * PDIV) >> 16 for pidx < PROWS (checked on the host)
 constexpr int C = 32;
 constexpr int W_FLOATS = 9 * C * C;         // 9216
 constexpr int P_FLOATS = PROWS * C;         // 10496
@@ -53,7 +60,7 @@ __device__ __forceinline__ u32x4 rsrc_words(const void* base, unsigned bytes) {
 }
 }  // namespace
 
-__global__ __launch_bounds__(512) void conv3x3_c32_patch_kernel(ConvLaunch p, int tiles_x, int tiles_per_img, int n_tiles) {
+__global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p, int tiles_x, int tiles_per_img, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* w_lds = smem;                                  // [9*32 rows][32]
   float* patch0 = smem + W_FLOATS;                      // 2 x [328 rows][32]
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(512) void conv3x3_c32_patch_kernel(ConvLaunch p, in
       __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((size_t)M * C * sizeof(float)), 0x00020000);
 
   // ---- weights -> LDS once (row = tap*32 + n, swizzle by n)
-  for (int k = wave; k < W_INSTR; k += 8) {
+  for (int k = wave; k < W_INSTR; k += NW) {
     const int e = k * 64 + lane;
     const int row = e >> 3, cpos = e & 7;
     const int n = row & 31, tap = row >> 5;
@@ -94,14 +101,14 @@ __global__ __launch_bounds__(512) void conv3x3_c32_patch_kernel(ConvLaunch p, in
   }
 
   // ---- per-lane constants of the patch DMA: which patch pixel / channel chunk each of my pieces is
-  constexpr int MAXP = (PATCH_INSTR + 7) / 8;   // 6 instructions per wave at most
+  constexpr int MAXP = (PATCH_INSTR + NW - 1) / NW;   // 6 (5) instructions per wave at most
   int pc_py[MAXP], pc_px[MAXP], pc_c4[MAXP];
 #pragma unroll
   for (int j = 0; j < MAXP; ++j) {
-    const int k = wave + 8 * j;
+    const int k = wave + NW * j;
     const int e = k * 64 + lane;
     const int pidx = e >> 3, cpos = e & 7;
-    const int py = (pidx * 3641) >> 16;       // pidx / 18 for pidx < 400
+    const int py = (pidx * PDIV) >> 16;       // pidx / PW
     pc_py[j] = (k < PATCH_INSTR && pidx < PPIX) ? py : -1000;
     pc_px[j] = pidx - py * PW;
     pc_c4[j] = cpos ^ ((pidx >> 1) & 7);
@@ -120,13 +127,13 @@ __global__ __launch_bounds__(512) void conv3x3_c32_patch_kernel(ConvLaunch p, in
     if (c < 0) { --ty; c += tiles_x; }
     if (c >= tiles_x) { ++ty; c -= tiles_x; }
     row0 = img * H;
-    y0 = ty * T;
-    x0 = c * T;
+    y0 = ty * TY;
+    x0 = c * TX;
   };
 
   // one wave-level DMA instruction (j-th of this wave) of the patch of the tile with origin (row0, y0, x0)
   auto issue_piece = [&](int j, int row0, int y0, int x0, int buf) {
-    const int k = wave + 8 * j;
+    const int k = wave + NW * j;
     if (k < PATCH_INSTR) {     // wave-uniform
       const int gy = y0 - 1 + pc_py[j], gx = x0 - 1 + pc_px[j];
       const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
@@ -136,7 +143,9 @@ __global__ __launch_bounds__(512) void conv3x3_c32_patch_kernel(ConvLaunch p, in
   };
 
   // my output pixel inside the tile and its position in the patch (tap 0,0 = one up, one left)
-  const int ly = 2 * wave + (fr >> 4), lx = fr & 15;
+  // my output pixel inside the tile: the wave's 32 pixels are consecutive in the tile's raster order
+  const int lq = 32 * wave + fr;
+  const int ly = TX == 16 ? (lq >> 4) : lq / TX, lx = lq - ly * TX;
   const int pbase = ly * PW + lx;
   // weight fragment: row = tap*32 + fr (output channel fr), chunk (2q+fh) swizzled by fr
   int w_off[4];
@@ -213,7 +222,7 @@ __global__ __launch_bounds__(512) void conv3x3_c32_patch_kernel(ConvLaunch p, in
 #ifdef UTP_NO_ROTATE
   const bool late = false;
 #else
-  const bool late = wave >= 4;        // wave is uniform (readfirstlane)
+  const bool late = ((wave >> 2) & 1) != 0;   // waves w, w+4(, w+8) share a SIMD; wave is uniform (readfirstlane)
 #endif
   bool have_prev = false;
   int prev_m = 0;
@@ -302,13 +311,13 @@ __global__ __launch_bounds__(512) void conv3x3_c32_patch_kernel(ConvLaunch p, in
 
 bool conv_patch_applicable(const ConvLaunch& c) {
   return c.ksize == 3 && c.stride == 1 && c.pad == 1 && c.cin == C && c.cout_store == C && c.cslice == C &&
-         c.k_pad == 9 * C && c.H % T == 0 && c.W % T == 0 && !c.out_nchw && c.H == c.Ho && c.W == c.Wo &&
+         c.k_pad == 9 * C && c.H % TY == 0 && c.W % TX == 0 && !c.out_nchw && c.H == c.Ho && c.W == c.Wo &&
          (size_t)c.n_img * c.H * c.W * C * sizeof(float) < 0x7FFFFF00ull;
 }
 
 hipError_t launch_conv_patch(const ConvLaunch& c, hipStream_t s) {
   if (!conv_patch_applicable(c) || !c.tile_counter || c.num_cu <= 0) return hipErrorInvalidValue;
-  const int tiles_x = c.W / T, tiles_per_img = tiles_x * (c.H / T);
+  const int tiles_x = c.W / TX, tiles_per_img = tiles_x * (c.H / TY);
   const int n_tiles = c.n_img * tiles_per_img;
   const size_t lds = (size_t)(W_FLOATS + 2 * P_FLOATS) * sizeof(float) + 16;
   static bool attr_set = false;
@@ -320,7 +329,7 @@ hipError_t launch_conv_patch(const ConvLaunch& c, hipStream_t s) {
   }
   int grid = c.num_cu;           // one 512-thread workgroup per CU (LDS: 121 KB)
   if (grid > n_tiles) grid = n_tiles;
-  hipLaunchKernelGGL(conv3x3_c32_patch_kernel, dim3(grid), dim3(512), lds, s, c, tiles_x, tiles_per_img, n_tiles);
+  hipLaunchKernelGGL(conv3x3_c32_patch_kernel, dim3(grid), dim3(64 * NW), lds, s, c, tiles_x, tiles_per_img, n_tiles);
   return hipGetLastError();
 }
 

@@ -47,7 +47,7 @@ convs = [r for r in rows if is_conv(r)]
 last = convs[-len(seq):]
 agg = collections.OrderedDict()
 for (nm, fl), r in zip(seq, last):
-    tile = r["Kernel_Name"].split("<")[1].split(">")[0] if "<" in r["Kernel_Name"] else "halo patch 16x16"
+    tile = r["Kernel_Name"].split("<")[1].split(">")[0] if "<" in r["Kernel_Name"] else "halo patch 16x24"
     a = agg.setdefault(nm, [0, 0.0, 0.0, tile])
     a[0] += 1; a[1] += dur(r); a[2] += fl
 tot_t = sum(a[1] for a in agg.values()); tot_f = sum(a[2] for a in agg.values())
