@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
   // Finer interleave (UT_FINE_FETCH): one 1-KB piece in front of every MFMA quad instead of three bursts.
   // The per-chunk tap arithmetic is done with piece 0 and kept in f_tap_off / f_dst.
   int f_tap_off = 0, f_dy = 0, f_dx = 0;
-  unsigned f_dst = 0;
+  unsigned f_dst = 0, f_off = 0;
 #define UT_FETCH_PIECE(IDX, DSTBUF)                                                                  \
   {                                                                                                  \
     if ((IDX) == 0) {                                                                                \
@@ -244,6 +244,40 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     } else if constexpr ((IDX) < AP + BP) {                                                          \
       constexpr int i = (IDX) - AP;                                                                  \
       UT_DIAG_B(dma16(b_words, f_dst + (BM + 32 * i) * LDS_ROW * 4, b_off + i * b_row_step));        \
+    }                                                                                                \
+    if ((IDX) == AP + BP - 1) { /* advance to the next chunk */                                      \
+      b_off += BK * 4;                                                                               \
+      ch += BK;                                                                                      \
+      if (ch >= p.cslice) { ch -= p.cslice; ++tap; }                                                 \
+      if (tap >= taps) { tap -= taps; ch_base += p.cslice; }                                         \
+    }                                                                                                \
+  }
+
+  // the same piece in two halves: the per-lane offset (vector ALU) and the transfer itself, so that each half can
+  // sit in its own MFMA gap
+#define UT_PIECE_ADDR(IDX, DSTBUF)                                                                   \
+  {                                                                                                  \
+    if ((IDX) == 0) {                                                                                \
+      f_dy = 0; f_dx = 0;                                                                            \
+      if (p.ksize == 3) { f_dy = (tap * 11) >> 5; f_dx = tap - 3 * f_dy; }                           \
+      f_tap_off = (f_dy * p.W + f_dx) * p.cin + ch_base + ch;                                        \
+      f_dst = smem_addr + (unsigned)(((DSTBUF) * STAGE + 8 * wave_u * LDS_ROW) * 4);                 \
+    }                                                                                                \
+    if constexpr ((IDX) < AP) {                                                                      \
+      constexpr int i = (IDX);                                                                       \
+      const int iy = a_iy[i] + f_dy, ix = a_ix[i] + f_dx;                                            \
+      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;                  \
+      f_off = ok ? (unsigned)(a_pix[i] + f_tap_off) * 4u : OOB;                                      \
+    } else if constexpr ((IDX) < AP + BP) {                                                          \
+      f_off = b_off + ((IDX) - AP) * b_row_step;                                                     \
+    }                                                                                                \
+  }
+#define UT_PIECE_ISSUE(IDX)                                                                          \
+  {                                                                                                  \
+    if constexpr ((IDX) < AP) {                                                                      \
+      UT_DIAG_A(dma16(a_words, f_dst + 32 * (IDX) * LDS_ROW * 4, f_off));                            \
+    } else if constexpr ((IDX) < AP + BP) {                                                          \
+      UT_DIAG_B(dma16(b_words, f_dst + (BM + 32 * ((IDX) - AP)) * LDS_ROW * 4, f_off));              \
     }                                                                                                \
     if ((IDX) == AP + BP - 1) { /* advance to the next chunk */                                      \
       b_off += BK * 4;                                                                               \
@@ -350,8 +384,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
   // Fine interleave: one LDS-DMA piece in front of every MFMA step (a step = one k of all MI*NI accumulators),
   // instead of three bursts per chunk: a piece issued among bare MFMAs costs the issuing wave ~60 cycles, one
   // issued next to other pieces and the fragment reads 100-185 (MI355X_MICROARCH.md, LDS-DMA piece issue cost).
+#ifndef UT_WHOLE_STEP     /* the piece's offset arithmetic and its transfer sit in different MFMA gaps (+1.1..1.5 %):
+                             in-order issue stalls the wave's next MFMA only by what exceeds one 64-cycle gap */
+#define UT_STEP_FINE(SET, C, IDX, DSTBUF)                                                            \
+  {                                                                                                  \
+    UT_PIECE_ADDR(IDX, DSTBUF); UT_PIN();                                                            \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[0].C, af##SET[0].C, acc[0][0], 0, 0, 0); \
+    UT_PIN(); UT_PIECE_ISSUE(IDX); UT_PIN();                                                         \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
+      _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                 \
+        if (i + j > 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[j].C, af##SET[i].C, acc[i][j], 0, 0, 0); \
+    UT_PIN();                                                                                        \
+  }
+#else
 #define UT_STEP_FINE(SET, C, IDX, DSTBUF)                                                            \
   { UT_FETCH_PIECE(IDX, DSTBUF); UT_PIN(); UT_MFMA_STEP(SET, C) UT_PIN(); }
+#endif
 #define UT_GROUP_FINE(SET, G, DSTBUF)                                                                \
   {                                                                                                  \
     UT_STEP_FINE(SET, x, 4 * (G) + 0, DSTBUF) UT_STEP_FINE(SET, y, 4 * (G) + 1, DSTBUF)              \
@@ -574,6 +622,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
 #undef UT_GROUP_FINE
 #undef UT_CHUNK_FINE
 #undef UT_FETCH_PIECE
+#undef UT_PIECE_ADDR
+#undef UT_PIECE_ISSUE
 #undef UT_BARRIER
 #undef UT_MAYBE_STAGE
 }
