@@ -380,6 +380,48 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     UT_MFMA_STEP(SET, x) UT_MFMA_STEP(SET, y) UT_MFMA_STEP(SET, z) UT_MFMA_STEP(SET, w)              \
   }
 #define UT_PIN() __builtin_amdgcn_sched_barrier(0)
+  // One 16-byte quad (G4) of accumulator (I, J) of the tile (e_tm, e_tn): (ReLU) + store through a buffer
+  // descriptor (pixels beyond M and channel quads beyond cout get an out-of-range offset and are dropped).
+#define UT_EPI_PART(I, J, G4)                                                                        \
+  {                                                                                                  \
+    const int m = e_tm * BM + wm * (MI * 32) + (I) * 32 + fr;                                        \
+    const bool m_ok = m < M;                                                                         \
+    const int n = e_tn * BN + wn * (NI * 32) + (J) * 32 + 8 * (G4) + 4 * fh;                         \
+    float v[4];                                                                                      \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[I][J][4 * (G4) + k], e_floor);    \
+    if constexpr (!NCHW) {                                                                           \
+      const unsigned off = (m_ok && n < p.cout_store) ? (unsigned)(m * p.cout_store + n) * 4u : OOB; \
+      u32x4 pk;                                                                                      \
+      pk.x = __float_as_uint(v[0]); pk.y = __float_as_uint(v[1]);                                    \
+      pk.z = __float_as_uint(v[2]); pk.w = __float_as_uint(v[3]);                                    \
+      __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, off, 0, 0);                                 \
+    } else { /* NCHW (projection only): channel stride hw, one dword per channel */                  \
+      const int img = fast_div(m_ok ? m : 0, hw, inv_hw);                                            \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                \
+        const unsigned off = (m_ok && n + k < p.cout_store)                                          \
+                                 ? (unsigned)((img * p.cout_store + n + k) * hw + (m - img * hw)) * 4u : OOB; \
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[k]), o_rsrc, off, 0, 0);             \
+      }                                                                                              \
+    }                                                                                                \
+  }
+  // The last MFMA group of a tile, one accumulator after the other instead of round-robin: the quads of the
+  // accumulator that has just been finished are stored in the MFMA gaps of the next one, so that only the last
+  // accumulator's stores (a quarter or a half of the epilogue) stay exposed behind the matrix work.
+#define UT_Q_MFMA(SET, Q, C) acc[(Q) / NI][(Q) % NI] = __builtin_amdgcn_mfma_f32_32x32x2f32(        \
+      bf##SET[(Q) % NI].C, af##SET[(Q) / NI].C, acc[(Q) / NI][(Q) % NI], 0, 0, 0)
+#define UT_Q_STORE(Q, G4) if constexpr ((Q) >= 0) { UT_EPI_PART(((Q) < 0 ? 0 : (Q)) / NI, ((Q) < 0 ? 0 : (Q)) % NI, G4); }
+#define UT_TAIL_Q(SET, Q)                                                                            \
+  if constexpr ((Q) < MI * NI) {                                                                     \
+    UT_Q_MFMA(SET, Q, x); UT_PIN(); UT_Q_STORE((Q) - 1, 0); UT_PIN();                                \
+    UT_Q_MFMA(SET, Q, y); UT_PIN(); UT_Q_STORE((Q) - 1, 1); UT_PIN();                                \
+    UT_Q_MFMA(SET, Q, z); UT_PIN(); UT_Q_STORE((Q) - 1, 2); UT_PIN();                                \
+    UT_Q_MFMA(SET, Q, w); UT_PIN(); UT_Q_STORE((Q) - 1, 3); UT_PIN();                                \
+  }
+#define UT_TAIL_EPI(SET)                                                                             \
+  {                                                                                                  \
+    UT_TAIL_Q(SET, 0) UT_TAIL_Q(SET, 1) UT_TAIL_Q(SET, 2) UT_TAIL_Q(SET, 3)                          \
+    UT_Q_STORE(MI * NI - 1, 0); UT_Q_STORE(MI * NI - 1, 1); UT_Q_STORE(MI * NI - 1, 2); UT_Q_STORE(MI * NI - 1, 3); \
+  }
 
   // Fine interleave: one LDS-DMA piece in front of every MFMA step (a step = one k of all MI*NI accumulators),
   // instead of three bursts per chunk: a piece issued among bare MFMAs costs the issuing wave ~60 cycles, one
@@ -428,8 +470,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     UT_STEP_INIT(X, x, 0, TILE) UT_STEP_INIT(X, y, 1, TILE) UT_STEP_INIT(X, z, 2, TILE) UT_STEP_INIT(X, w, 3, TILE) \
     UT_MAYBE_STAGE((buf) ^ 1);                                                                       \
     UT_BARRIER();                                                                                    \
-    UT_READ(X, (buf) ^ 1, 0); UT_PIN(); UT_MFMA(Y); UT_PIN();                                        \
+    UT_READ(X, (buf) ^ 1, 0); UT_PIN(); UT_TAIL_MFMA(Y); UT_PIN();                                   \
   }
+#ifdef UT_PLAIN_TAIL      /* diag: round-robin last group, epilogue behind it */
+#define UT_TAIL_MFMA(SET) UT_MFMA(SET)
+#else
+#define UT_TAIL_MFMA(SET) { UT_TAIL_EPI(SET); epi_done = true; }
+#endif
   // One chunk, software pipelined against LDS latency and the barrier.  On entry set X holds the q=0
   // fragments of this chunk (read under the previous chunk's last MFMA group).  The reads of group q+1 are
   // issued before the MFMAs of group q; the next chunk is staged and the barrier passed BEFORE the last
@@ -522,6 +569,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     // last chunk: fetch the first chunk, bias and residual of the NEXT tile under it (without a next tile the
     // staging inside UT_CHUNK rewrites stale registers into the idle buffer: harmless)
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int e_tm = tm, e_tn = tn;
+    const float e_floor = p.relu ? 0.f : -__builtin_huge_valf();   // 0 with ReLU, -inf without: one v_max, no branch
+    bool epi_done = false;
     if (n_chunks <= 2) {                  // too few chunk barriers to order the queue slot: do it explicitly
       if (n_chunks == 1 && tid == 0) UT_SLOT_WRITE(grid + ticket);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -554,41 +604,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     // epilogue of the finished tile: (ReLU) + store through a buffer descriptor (pixels beyond M and channel
     // quads beyond cout get an out-of-range offset and are dropped): straight-line 16-byte stores, so the
     // compiler counts them exactly instead of draining the memory pipe before the next tile.
-    const int m0 = tm * BM, n0 = tn * BN;
-    const float relu_floor = p.relu ? 0.f : -__builtin_huge_valf();
+    if (!epi_done) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int m = m0 + wm * (MI * 32) + i * 32 + fr;
-      const bool m_ok = m < M;
-      const int img = NCHW ? fast_div(m_ok ? m : 0, hw, inv_hw) : 0;
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int n = n0 + wn * (NI * 32) + j * 32 + 8 * g4 + 4 * fh;
-          float v[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            v[k] = acc[i][j][4 * g4 + k];
-            v[k] = fmaxf(v[k], relu_floor);   // 0 with ReLU, -inf without: one v_max, no branch
-          }
-          if constexpr (!NCHW) {
-            const unsigned off = (m_ok && n < p.cout_store) ? (unsigned)(m * p.cout_store + n) * 4u : OOB;
-            u32x4 pk;
-            pk.x = __float_as_uint(v[0]); pk.y = __float_as_uint(v[1]);
-            pk.z = __float_as_uint(v[2]); pk.w = __float_as_uint(v[3]);
-            __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, off, 0, 0);
-          } else {
-            // NCHW (projection only): channel stride hw, one dword per channel
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const unsigned off = (m_ok && n + k < p.cout_store)
-                                       ? (unsigned)((img * p.cout_store + n + k) * hw + (m - img * hw)) * 4u : OOB;
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[k]), o_rsrc, off, 0, 0);
-            }
-          }
+        for (int j = 0; j < NI; ++j) {
+          UT_EPI_PART(i, j, 0); UT_EPI_PART(i, j, 1); UT_EPI_PART(i, j, 2); UT_EPI_PART(i, j, 3);
         }
-      }
     }
 #ifdef UT_STAMPS
     if (tiles_done == 0) UT_STAMP(4);
@@ -614,6 +636,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
 #undef UT_MFMA
 #undef UT_MFMA_STEP
 #undef UT_PIN
+#undef UT_EPI_PART
+#undef UT_Q_MFMA
+#undef UT_Q_STORE
+#undef UT_TAIL_Q
+#undef UT_TAIL_EPI
+#undef UT_TAIL_MFMA
 #undef UT_STEP_FINE
 #undef UT_GROUP_FINE_R
 #undef UT_STEP_INIT
