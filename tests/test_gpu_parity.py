@@ -218,3 +218,31 @@ def test_warp_matches_oracle(engine, mode):
         assert diff.max() <= 8.0 / 255.0
     else:
         assert diff.max() < 1e-4
+
+
+def test_alternative_kernel_paths_agree():
+    """The env-selected alternatives of the convolution dispatch (register-staged operands instead of LDS-DMA, the
+    generic kernel instead of the halo-patch kernel, vector instead of scalar tap bookkeeping, full-height tiles for
+    the head, one tile per workgroup instead of the persistent queue) compute the same features.  The switches are
+    read once per process, hence subprocesses."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r);"
+            "from absolutetrack_amd import _native, synth;"
+            "eng = _native.HipEngine(synth.synthetic_state_dict(0), 'cuda:0');"
+            "x = torch.from_numpy(synth.synthetic_crops(5, seed=3)).to('cuda:0');"
+            "f = eng.backbone(x).double().cpu();"
+            "print('FEAT', ' '.join(repr(float(v)) for v in [f.sum(), f.abs().sum(), (f * f).sum(), f[3].sum()]))") % root
+    outs = {}
+    for name, env in (("default", {}), ("no_dma", {"UT_CONV_DMA": "0"}), ("no_patch", {"UT_CONV_PATCH": "0"}),
+                      ("no_c32", {"UT_CONV_C32": "0"}), ("no_small_m", {"UT_CONV_SMALL_M": "0"}),
+                      ("no_persist", {"UT_PERSIST_LIMIT": "-1"})):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                           env={**os.environ, **env})
+        assert r.returncode == 0, (name, r.stderr[-1500:])
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("FEAT")][0]
+        outs[name] = np.array([float(v) for v in line.split()[1:]])
+    for name, v in outs.items():
+        np.testing.assert_allclose(v, outs["default"], rtol=1e-6, err_msg=name)
