@@ -8,6 +8,7 @@
 Video decoding (PyAV) is out of scope: `SyncedImagePoseStream` takes any iterable of mono frames; asking it to open
 an mp4 raises ImportError when PyAV is not installed, exactly like importing the reference's module would.
 """
+import enum
 import io
 import json
 import math
@@ -140,6 +141,15 @@ class SyncedImagePoseStream:
 
 # ----------------------------------------------------------------------------- .torch.idx / .torch.bin
 IDX_MAGIC = 0x584449544E54
+OBJECT_DTYPE = np.dtype("object")
+MsgpackObject = Dict[str, Any]
+RawField = Union[np.ndarray, MsgpackObject]
+
+
+class BinFormat(enum.Enum):
+    TENSOR = 0
+    MSGPACK = 1
+
 _CODE_TO_DTYPE = {1: "uint8", 2: "int8", 3: "int16", 4: "int32", 5: "int64", 6: "float32", 7: "float64", 8: "object"}
 _DTYPE_TO_CODE = {v: k for k, v in _CODE_TO_DTYPE.items()}
 Buffer = Union[bytes, bytearray, memoryview]
@@ -208,6 +218,11 @@ class TorchIdx:
 
     def byte_offset(self, i: int) -> int:
         return int(self._byte_offsets[len(self) if i == -1 else i])
+
+    def byte_offsets(self, start: int, end: int) -> np.ndarray:
+        """Byte offsets of frames start..end-1 (`end` may be N+1 or -1: one past the last frame's start), the span
+        form the reference's async reader asks for (lib/data_utils/idxbinfile.py:213-231)."""
+        return self._byte_offsets[start: len(self) + 1 if end == -1 else end]
 
     def data_size_bytes(self) -> int:
         return self.byte_offset(-1) - self.byte_offset(0)

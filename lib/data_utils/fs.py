@@ -1,5 +1,6 @@
 """lib/data_utils/fs.py of the reference: POSIX-like path/file helpers the eval scripts call
-(walk, join, exists, dirname, open).  `join` always treats the trailing parts as relative, like the
+(walk, join, exists, dirname, open, read_bytes / aread_bytes -- the two the reference's own dataset
+loader calls, lib/data_utils/fs.py:67-91).  `join` always treats the trailing parts as relative, like the
 reference's (lib/data_utils/fs.py:25-52)."""
 import io
 import os
@@ -34,3 +35,15 @@ def dirname(path):
 
 def makedirs(p):
     os.makedirs(p, exist_ok=True)
+
+
+def read_bytes(path, start=0, stop=None) -> bytes:
+    """File contents, or the byte span [start, stop)."""
+    with io.open(path, "rb") as f:
+        if start:
+            f.seek(start)
+        return f.read() if stop is None else f.read(stop - start)
+
+
+async def aread_bytes(path, start=0, stop=None) -> bytes:
+    return read_bytes(path, start, stop)
