@@ -300,16 +300,43 @@ def shard_frames(n_frames_total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_records(local: torch.Tensor, world: int) -> torch.Tensor:
-    """All-gather equal-sized [S_local, R] record blocks into [world*S_local, R] on every rank
-    (RCCL over xGMI when the process group is 'nccl'; 'gloo' in the CPU tests)."""
+def gather_records(local: torch.Tensor, world: int, equal_counts: bool = False) -> torch.Tensor:
+    """All-gather the per-rank [S_local, R] record blocks into the rank-ordered [sum S_local, R] on every rank
+    (RCCL over xGMI when the process group is 'nccl'; 'gloo' in the CPU tests).
+
+    Ranks may hold different numbers of records: `shard_frames` hands out blocks that differ by one frame, and a
+    hand dropped by the confidence / visibility gate (lib/tracker/tracker.py:236-241, perspective_crop.py:168-178)
+    shortens one rank's block.  So the counts are exchanged first (one 8-byte all-gather), every block is padded to the
+    longest, gathered with ONE all_gather_into_tensor, and the padding is trimmed.  `equal_counts=True` skips the count
+    exchange when the caller knows the blocks are equal (bench.py: equal frame blocks, two confident hands per frame)
+    and lets a mismatch fail loudly in the collective's own size check instead of hanging."""
     if world == 1:
         return local
     import torch.distributed as dist
-    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    if dist.get_backend() == "gloo":
-        parts = list(out.chunk(world, 0))
-        dist.all_gather(parts, local.contiguous())
+    local = local.contiguous()
+    tail = tuple(local.shape[1:])
+    if equal_counts:
+        counts = [local.shape[0]] * world
     else:
-        dist.all_gather_into_tensor(out, local.contiguous())
-    return out
+        mine = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+        allc = torch.empty(world, dtype=torch.int64, device=local.device)
+        _all_gather_flat(allc, mine, world)
+        counts = [int(c) for c in allc.tolist()]
+    longest = max(counts)
+    if local.shape[0] != longest:
+        padded = local.new_zeros((longest,) + tail)
+        padded[: local.shape[0]] = local
+        local = padded
+    out = torch.empty((world * longest,) + tail, dtype=local.dtype, device=local.device)
+    _all_gather_flat(out, local, world)
+    if all(c == longest for c in counts):
+        return out
+    return torch.cat([out[r * longest: r * longest + c] for r, c in enumerate(counts)], 0)
+
+
+def _all_gather_flat(out: torch.Tensor, local: torch.Tensor, world: int) -> None:
+    import torch.distributed as dist
+    if dist.get_backend() == "gloo":       # gloo has no all_gather_into_tensor
+        dist.all_gather(list(out.chunk(world, 0)), local)
+    else:
+        dist.all_gather_into_tensor(out, local)

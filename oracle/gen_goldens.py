@@ -152,6 +152,14 @@ def export_labels():
     return d
 
 
+def export_generic_hand_model():
+    """dataset/generic_hand_model.json (the skeleton run_eval_unknown_skeleton.py:146-147 calibrates) without its mesh."""
+    d = json.load(open(os.path.join(REF, "dataset", "generic_hand_model.json")))
+    out = {k: np.asarray(v, np.int64 if k == "landmark_rest_bone_indices" else np.float32) for k, v in d.items()
+           if not k.startswith("mesh_") and k != "dense_bone_weights"}
+    np.savez_compressed(os.path.join(DATA, "generic_hand_model.npz"), **out)
+
+
 def export_fk():
     out = {}
     for rec in ("00", "02", "11"):
@@ -290,6 +298,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     labels = export_labels()
+    export_generic_hand_model()
     export_fk()
     export_geometry(labels)
     export_torch_data()

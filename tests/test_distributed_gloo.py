@@ -1,7 +1,9 @@
-"""world_size-2 `gloo` test of the multi-GPU path on CPU: contiguous frame sharding + all-gather of the
+"""world_size 2 and 3 `gloo` tests of the multi-GPU path on CPU: contiguous frame sharding + all-gather of the
 per-hand records (the only communication of the path; RCCL on the GPU node, gloo here).  The per-rank
 compute is a deterministic stand-in (the HIP kernels cannot run on CPU); what is checked is that the
-gathered tensor is the rank-ordered concatenation of the shards, i.e. frame order is preserved."""
+gathered tensor is the rank-ordered concatenation of the shards, i.e. frame order is preserved - also when the
+frame count does not divide by the world size and when a rank lost a hand to the confidence / visibility gate
+(SURVEY.md section 8 e; the reference's only distribution idiom is lib/data_utils/async_dataset.py:546-559)."""
 import os
 import socket
 import sys
@@ -21,39 +23,54 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_frames, q):
+def _worker(rank, world, port, n_frames, q, dropped=(), equal_counts=False):
     sys.path.insert(0, ROOT)
     from absolutetrack_amd import pipeline
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = pipeline.shard_frames(n_frames, rank, world)
-    # stand-in records: 2 hands per frame, record[k] = global hand-frame index + k/1000
-    s_local = 2 * (hi - lo)
-    idx = torch.arange(2 * lo, 2 * hi, dtype=torch.float32)
+    # stand-in records: 2 hands per frame minus the dropped ones, record[k] = global hand-frame index + k/1000
+    idx = torch.tensor([i for i in range(2 * lo, 2 * hi) if i not in dropped], dtype=torch.float32)
     rec = idx[:, None] + torch.arange(pipeline.RECORD, dtype=torch.float32)[None] / 1000.0
-    assert rec.shape == (s_local, pipeline.RECORD)
-    out = pipeline.gather_records(rec, world)
-    q.put((rank, out[:, 0].tolist(), tuple(out.shape)))
+    try:
+        out = pipeline.gather_records(rec, world, equal_counts=equal_counts)
+        q.put((rank, out[:, 0].tolist(), tuple(out.shape), bool(torch.equal(out[:, 1], out[:, 0] + 0.001))))
+    except Exception as e:                   # noqa: BLE001 - reported to the parent
+        q.put((rank, repr(e), None, False))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_gather_records_preserves_frame_order_world2():
-    world, n_frames = 2, 12
+def _run(world, n_frames, dropped=(), equal_counts=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, q, dropped, equal_counts)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=120) for _ in range(world)]
+    results = [q.get(timeout=180) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for _rank, col0, shape in results:
-        assert shape == (2 * n_frames, 123)
-        assert col0 == [float(i) for i in range(2 * n_frames)]     # every rank holds all records, in frame order
+    return results
+
+
+def test_gather_records_preserves_frame_order_world2():
+    world, n_frames = 2, 12
+    for equal_counts in (False, True):
+        for _rank, col0, shape, ok in _run(world, n_frames, equal_counts=equal_counts):
+            assert shape == (2 * n_frames, 123) and ok
+            assert col0 == [float(i) for i in range(2 * n_frames)]     # every rank holds all records, in frame order
+
+
+def test_gather_records_unequal_shards():
+    """F % world != 0 (blocks differ by one frame) at world 2 and 3, and one hand dropped on one rank."""
+    for world, n_frames, dropped in ((2, 7, ()), (3, 10, ()), (3, 11, (5,)), (2, 6, (0, 11)), (3, 2, ())):
+        want = [float(i) for i in range(2 * n_frames) if i not in dropped]
+        for _rank, col0, shape, ok in _run(world, n_frames, dropped):
+            assert shape == (len(want), 123) and ok, (world, n_frames, dropped, col0)
+            assert col0 == want
 
 
 def test_gather_records_single_rank_is_identity():

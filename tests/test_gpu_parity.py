@@ -35,6 +35,26 @@ def test_library_is_the_in_tree_build(engine):
     assert os.path.samefile(engine.lib._name, _native.LIB_PATH)
 
 
+def test_load_pretrained_model_file_to_engine(engine, tmp_path):
+    """File -> load_pretrained_model -> .to('cuda') -> native handle (lib/models/model_loader.py:53-88,
+    lib/tracker/tracker.py:97-98): same features, bit for bit, as the handle built from the in-memory weights."""
+    from lib.models.model_loader import load_pretrained_model
+    from lib.models.umetrack_model import InputFrameData, InputFrameDesc
+    path = str(tmp_path / "w.torch")
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in synth.synthetic_state_dict(0).items()}, path)
+    m = load_pretrained_model(path)
+    m.eval()
+    m.to("cuda")
+    crops = _dev(synth.synthetic_crops(4, seed=8))
+    assert torch.equal(m.engine.backbone(crops), engine.backbone(crops))
+    fd = InputFrameData(crops, torch.tensor([[130.0, 0, 47.5], [0, 130.0, 47.5], [0, 0, 1]]).repeat(4, 1, 1),
+                        torch.eye(4).repeat(4, 1, 1))
+    desc = InputFrameDesc(torch.tensor([[0, 2], [2, 4]]), torch.tensor([0, 1]), torch.tensor([False, False]),
+                          torch.tensor([0, 1]))
+    out = m.regress_pose_pred_skel_scale(fd, desc)
+    assert out.joint_angles.shape == (2, 22) and out.skel_scales.shape == (2,) and out.wrist_xfs.device.type == "cuda"
+
+
 def test_backbone_matches_oracle(engine):
     crops = synth.synthetic_crops(7, seed=3)
     taps = {}
@@ -178,6 +198,60 @@ def test_fk_per_pose_models_and_empty(engine):
                    landmark_rest_positions=hm["landmark_rest_positions"] * s)
         assert np.abs(kp[i] - ref_fk.skin_landmarks(hmi, ja[i], xf[i])).max() < 2e-4
     assert engine.fk(_dev(blobs[:1]), torch.empty(0, 22, device=DEV), torch.empty(0, 4, 4, device=DEV)).shape == (0, 21, 3)
+
+
+def test_fk_multi_bone_blend_and_duplicate_bone_entries(engine, golden_dir):
+    """Linear blend skinning with 2-3 non-zero bone weights per landmark (lib/common/hand_skinning.py:56-97).
+    In every model the reference ships, landmark 20 (palm centre) blends three bones (weights .887/.077/.036 on
+    frames 1, 8, 5) and the other 20 landmarks have one: so the 3-bone blend is pinned by the stored gt_keypoints of
+    test_fk_matches_stored_reference_keypoints (checked here for that landmark alone).  This test widens it to every
+    landmark on a synthetic model, GPU vs oracle, including two non-zero entries that name the SAME bone: the
+    reference's dense scatter `skin_mat[idx] = w` keeps one of them - the last one on the CPU, which is what both
+    the oracle and the kernel implement (torch calls duplicate indices in index_put_ undefined: parity unpinned)."""
+    g = np.load(os.path.join(golden_dir, "fk_user05.npz"))
+    hm0 = {k[len("r00.hm."):]: g[k] for k in g.files if k.startswith("r00.hm.")}
+    assert (hm0["landmark_rest_bone_weights"] != 0).sum(1).tolist() == [1] * 20 + [3]
+    rng = np.random.default_rng(5)
+    n = 64
+    w = rng.uniform(0.1, 1.0, (n, 21, 3)).astype(np.float32)
+    idx = rng.integers(0, 17, (n, 21, 3)).astype(np.int64)
+    w[:, ::3, 2] = 0                      # two bones only
+    w[:, 1::5, 0] = 0                     # a zero in front of non-zeros
+    idx[:, 2::4, 2] = idx[:, 2::4, 0]     # duplicate bone, both weights non-zero: the later entry wins
+    idx[:, 3::7, 1] = idx[:, 3::7, 2]
+    w /= w.sum(-1, keepdims=True)
+    assert ((w != 0).sum(-1) >= 2).all()
+    hm = dict(hm0, landmark_rest_bone_weights=w, landmark_rest_bone_indices=idx,
+              joint_rotation_axes=np.broadcast_to(hm0["joint_rotation_axes"], (n, 22, 3)),
+              joint_rest_positions=np.broadcast_to(hm0["joint_rest_positions"], (n, 22, 3)),
+              landmark_rest_positions=np.broadcast_to(hm0["landmark_rest_positions"], (n, 21, 3)))
+    sel = rng.integers(0, g["r00.joint_angles"].shape[0], n)
+    ja = g["r00.joint_angles"][sel, 0].astype(np.float32)
+    xf = g["r00.wrist_transforms"][sel, 0].astype(np.float32)
+    blobs = _native.hand_model_blob(hm["joint_rotation_axes"], hm["joint_rest_positions"], hm["landmark_rest_positions"],
+                                    w, idx)
+    assert blobs.shape == (n, 321)
+    kp = engine.fk(_dev(blobs), _dev(ja), _dev(xf)).cpu().numpy()
+    want = ref_fk.skin_landmarks(hm, ja, xf)
+    assert np.abs(kp - want).max() < 2e-4                                  # mm
+    # the duplicate really matters: dropping the later entry instead changes the result
+    w_first = w.copy()
+    w_first[:, 2::4, 2] = 0
+    other = ref_fk.skin_landmarks(dict(hm, landmark_rest_bone_weights=w_first), ja, xf)
+    assert np.abs(other - want)[:, 2::4].max() > 1.0
+    # one shared multi-bone model for the whole batch (n_models == 1)
+    kp1 = engine.fk(_dev(blobs[:1]), _dev(ja), _dev(xf)).cpu().numpy()
+    hm1 = {k: (v[0] if v.ndim == 3 and v.shape[0] == n else v) for k, v in hm.items()}
+    assert np.abs(kp1 - ref_fk.skin_landmarks(hm1, ja, xf)).max() < 2e-4
+    # the reference's own 3-bone landmark against its stored output
+    ja0, xf0 = g["r00.joint_angles"].astype(np.float32), g["r00.wrist_transforms"].astype(np.float32)
+    blob0 = _native.hand_model_blob(hm0["joint_rotation_axes"], hm0["joint_rest_positions"], hm0["landmark_rest_positions"],
+                                    hm0["landmark_rest_bone_weights"], hm0["landmark_rest_bone_indices"])[None]
+    t = ja0.shape[0]
+    kp0 = engine.fk(_dev(blob0), _dev(ja0.reshape(-1, 22)), _dev(xf0.reshape(-1, 4, 4)),
+                    mirror=_dev(np.tile(np.array([0, 1], np.int64), t))).cpu().numpy().reshape(t, 2, 21, 3)
+    valid = g["r00.valid_tracking"].T
+    assert np.abs(kp0[:, :, 20] - g["r00.gt_keypoints"].transpose(1, 0, 2, 3)[:, :, 20])[valid].max() < 1e-3
 
 
 def _rec00_cameras(lab, fi):

@@ -43,6 +43,34 @@ def test_state_dict_blob_is_strict():
         _native.state_dict_to_blob(bad)
 
 
+def test_load_pretrained_model_round_trip(tmp_path):
+    """lib/models/model_loader.py:84-87: a plain `torch.save`d state dict -> file -> UmeTrackModel, strict.  The file
+    is read with weights_only=True; a checkpoint with a missing / extra / mis-shaped entry is refused like
+    load_state_dict(strict=True) refuses it."""
+    from lib.models.model_loader import load_pretrained_model
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.synthetic_state_dict(0).items()}
+    path = str(tmp_path / "pretrained_weights.torch")
+    torch.save(sd, path)
+    m = load_pretrained_model(path)
+    assert isinstance(m, model.UmeTrackModel) and m.eval() is m
+    got = m.state_dict()
+    assert list(got) == [k for k, _s, _kind in arch.state_dict_spec()]
+    assert all(torch.equal(got[k], sd[k]) and got[k].dtype == sd[k].dtype for k in sd)
+    assert np.array_equal(_native.state_dict_to_blob(got), _native.state_dict_to_blob(synth.synthetic_state_dict(0)))
+    first = arch.state_dict_spec()[0][0]
+    for bad in ({k: v for k, v in sd.items() if k != first}, dict(sd, extra=torch.zeros(1)),
+                dict(sd, **{first: torch.zeros(32, 1, 5, 5)})):
+        torch.save(bad, path)
+        with pytest.raises(RuntimeError):
+            load_pretrained_model(path)
+    # an object that needs unpickling of arbitrary code is refused by the safe loader
+    import pickle
+    with open(path, "wb") as f:
+        pickle.dump({"w": np.zeros(3)}, f)
+    with pytest.raises(Exception):
+        load_pretrained_model(path)
+
+
 @pytest.mark.skipif(not NO_GPU, reason="checks the no-GPU failure mode")
 def test_no_cpu_fallback():
     m = model.UmeTrackModel(synth.synthetic_state_dict(0))
