@@ -21,10 +21,12 @@ EXPORTS = (
     "ut_set_backbone_chunk", "ut_warp_crops", "ut_backbone", "ut_fuse_temporal_regress",
     "ut_reset_memory", "ut_get_memory", "ut_fk", "ut_gen_crop_cameras", "ut_gen_crop_matrices",
     "ut_resample_homography", "ut_keypoint_metrics", "ut_profile_begin", "ut_profile_end",
+    "ut_set_index_checks", "ut_poll_status",
 )
 
 UT_MODE_KNOWN, UT_MODE_UNKNOWN = 0, 1
 UT_REMAP_CV2_FIXED, UT_REMAP_FLOAT = 0, 1
+UT_CHECK_SYNC, UT_CHECK_DEFERRED = 0, 1
 
 _lib = None
 
@@ -84,6 +86,10 @@ def load_library() -> ctypes.CDLL:
     lib.ut_profile_end.restype = i32
     lib.ut_profile_end.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
                                    ctypes.POINTER(ctypes.c_double)]
+    lib.ut_set_index_checks.restype = i32
+    lib.ut_set_index_checks.argtypes = [vp, i32]
+    lib.ut_poll_status.restype = i32
+    lib.ut_poll_status.argtypes = [vp, vp]
     _lib = lib
     return lib
 
@@ -331,8 +337,20 @@ class HipEngine:
             msg = self.lib.ut_last_error(self._h).decode()
             if rc == -4:
                 raise AssertionError(msg)      # the reference asserts here (umetrack_model.py:224-229)
+            if rc == -1 and "index check:" in msg:
+                raise IndexError(msg)          # the reference's tensor indexing raises IndexError on these
             raise RuntimeError(f"{what} failed ({rc}): {msg}")
         return rc
+
+    def set_index_checks(self, deferred: bool):
+        """Default: every call that takes index tensors reads the device-side verdict back (one stream sync) and
+        raises IndexError.  deferred=True: no sync (hipGraph capture, run-ahead launching); bad work is skipped on
+        the device and `poll_status()` raises for it later."""
+        self._check(self.lib.ut_set_index_checks(self._h, UT_CHECK_DEFERRED if deferred else UT_CHECK_SYNC),
+                    "ut_set_index_checks")
+
+    def poll_status(self):
+        self._check(self.lib.ut_poll_status(self._h, _stream(self.device)), "ut_poll_status")
 
     # ------------------------------------------------------------------ entry points
     def reserve(self, max_crops: int, max_samples: int, max_slots: int):

@@ -34,6 +34,8 @@
 // tiles (projection and head: 74 k pixels); layer1 (3x3, 32 -> 32) runs in conv_patch.hip instead.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "ut_kernels.h"
 
 namespace ut {
@@ -663,12 +665,14 @@ static hipError_t launch_cfg(const ConvLaunch& c, hipStream_t s) {
   const int tiles_n = (c.cout_store + BN - 1) / BN;
   const int n_tiles = tiles_m * tiles_n;
   const size_t lds = 2 * (size_t)(BM + BN) * lds_row<DMA>() * sizeof(float) + 16;   // + tile-queue slot
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the attribute belongs to (kernel, device): one bit per device, set on the first launch there
+  static std::atomic<unsigned long long> attr_set{0};
+  const unsigned long long dev_bit = (c.device >= 0 && c.device < 64) ? 1ull << c.device : 0ull;
+  if (!(attr_set.load(std::memory_order_relaxed) & dev_bit) || !dev_bit) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, DMA, NCHW, C32>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.fetch_or(dev_bit, std::memory_order_relaxed);
   }
   // persistent grid: as many workgroups as stay resident (LDS bound), never more than tiles
   const int per_cu = (int)((160 * 1024) / lds);

@@ -14,6 +14,8 @@
 // lane owns one pixel and accumulator register quads are 4 consecutive channels (16-byte NHWC accesses).
 // LDS rows are 128 B (32 floats) with the 16-byte chunks XOR-swizzled by ((row >> 1) & 7), applied on the source
 // side of the DMA; rows are "pixel of the patch" resp. "(tap, output channel)".
+#include <atomic>
+
 #include "ut_kernels.h"
 
 namespace ut {
@@ -320,12 +322,14 @@ hipError_t launch_conv_patch(const ConvLaunch& c, hipStream_t s) {
   const int tiles_x = c.W / TX, tiles_per_img = tiles_x * (c.H / TY);
   const int n_tiles = c.n_img * tiles_per_img;
   const size_t lds = (size_t)(W_FLOATS + 2 * P_FLOATS) * sizeof(float) + 16;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the attribute belongs to (kernel, device): one bit per device, set on the first launch there
+  static std::atomic<unsigned long long> attr_set{0};
+  const unsigned long long dev_bit = (c.device >= 0 && c.device < 64) ? 1ull << c.device : 0ull;
+  if (!(attr_set.load(std::memory_order_relaxed) & dev_bit) || !dev_bit) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c32_patch_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.fetch_or(dev_bit, std::memory_order_relaxed);
   }
   int grid = c.num_cu;           // one 512-thread workgroup per CU (LDS: 121 KB)
   if (grid > n_tiles) grid = n_tiles;

@@ -15,11 +15,36 @@ namespace ut {
 
 constexpr int PIX = 36, FC = 72, MEMC = 18, TC = 92;
 
+// ---------------------------------------------------------------- descriptor checks
+// The reference indexes with these tensors in Python and raises IndexError / asserts on bad ones
+// (lib/models/temporal.py:101-137, lib/models/umetrack_model.py:149-166,224-229); here a bad entry sets a bit in
+// the status word and every kernel below returns before touching memory when an error bit is set.
+__global__ __launch_bounds__(256) void validate_desc_kernel(HeadArgs a) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= a.n_samples) return;
+  int bits = 0;
+  const long long r0 = a.sample_range[2 * s], r1 = a.sample_range[2 * s + 1];
+  const long long nv = r1 - r0;
+  if (r0 < 0 || r1 > a.n_crops || nv < 1 || nv > 2) bits |= UT_BAD_SAMPLE_RANGE;
+  else if (nv == 1) bits |= UT_SINGLE_VIEW;
+  const long long slot = a.memory_idx[s];
+  if (slot < 0 || slot >= a.n_slots) bits |= UT_BAD_MEMORY_IDX;
+  else if (atomicAdd(a.slot_seen + slot, 1) != 0) bits |= UT_DUP_MEMORY_IDX;
+  const long long hand = a.hand_idx[s];
+  if (hand != 0 && hand != 1) bits |= UT_BAD_HAND_IDX;
+  if (bits & UT_STATUS_ERRORS) atomicOr(a.status, bits & UT_STATUS_ERRORS);
+  if (bits & ~UT_STATUS_ERRORS) atomicOr(a.status + 1, bits & ~UT_STATUS_ERRORS);
+}
+#define UT_RETURN_IF_INVALID(a)                                                              \
+  if ((((volatile const int*)(a).status)[0] & UT_STATUS_ERRORS) ||                           \
+      (((volatile const int*)(a).status)[1] & (a).call_error_mask)) return
+
 // ---------------------------------------------------------------- FTL in (+ view concat)
 // One workgroup per sample.  Two-view samples: both views are moved to the canonical space with
 // A_v = S_0^-1 X_0 X_v^-1 S_v and written side by side (144 channels).  One-view samples: FTL
 // with S_v only, written straight to the fused buffer (the fusion convs are skipped for them).
 __global__ __launch_bounds__(256) void ftl_in_kernel(HeadArgs a, HeadBuffers b) {
+  UT_RETURN_IF_INVALID(a);
   const int s = blockIdx.x;
   const int r0 = (int)a.sample_range[2 * s], r1 = (int)a.sample_range[2 * s + 1];
   const int nv = r1 - r0;
@@ -80,6 +105,7 @@ __global__ __launch_bounds__(256) void ftl_in_kernel(HeadArgs a, HeadBuffers b) 
 // sample's slot is warped by cur_ext * prev_ext^-1 (or zeroed) and concatenated in front:
 // t92a[s][p] = [mem'(18) | fused(72) | 0 0].
 __global__ __launch_bounds__(256) void ftl_out_temporal_in_kernel(HeadArgs a, HeadBuffers b) {
+  UT_RETURN_IF_INVALID(a);
   const int s = blockIdx.x;
   const int r0 = (int)a.sample_range[2 * s], r1 = (int)a.sample_range[2 * s + 1];
   const int nv = r1 - r0;
@@ -126,6 +152,7 @@ __global__ __launch_bounds__(256) void ftl_out_temporal_in_kernel(HeadArgs a, He
 __global__ __launch_bounds__(256) void temporal_out_kernel(HeadArgs a, const float* __restrict__ t_out,
                                                            const float* __restrict__ skel, int n_skel,
                                                            float* __restrict__ regin, int reg_c) {
+  UT_RETURN_IF_INVALID(a);
   const int s = blockIdx.x;
   const int slot = (int)a.memory_idx[s];
   for (int it = threadIdx.x; it < PIX * TC; it += 256) {
@@ -201,6 +228,7 @@ __global__ __launch_bounds__(128) void pool_matvec_kernel(const float* __restric
 // 64 samples share a wave instead of one lane of a wave each.
 __global__ __launch_bounds__(64) void decode_kernel(HeadArgs a, const float* __restrict__ raw_in, int d,
                                                     float* __restrict__ out_pose) {
+  UT_RETURN_IF_INVALID(a);
   const int s = blockIdx.x * 64 + threadIdx.x;
   if (s >= a.n_samples) return;
   const float* raw = raw_in + (size_t)s * 64;
@@ -260,6 +288,10 @@ __global__ __launch_bounds__(64) void decode_kernel(HeadArgs a, const float* __r
 }
 
 // ---------------------------------------------------------------- launchers
+hipError_t launch_validate_desc(const HeadArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(validate_desc_kernel, dim3((a.n_samples + 255) / 256), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
 hipError_t launch_ftl_in(const HeadArgs& a, const HeadBuffers& b, hipStream_t s) {
   hipLaunchKernelGGL(ftl_in_kernel, dim3(a.n_samples), dim3(256), 0, s, a, b);
   return hipGetLastError();

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -78,6 +79,12 @@ struct ut_context {
   // tile-queue counters: one word per conv launch of a call, zeroed by one memset at the start of the call
   unsigned* counters = nullptr;
   int counter_next = 0;
+  // index checks: device status words ([0] sticky errors, [1] per call), their pinned host mirror, the duplicate-slot
+  // scratch (slots_cap ints, allocated with the temporal state) and the mode (UT_CHECK_*)
+  int* status = nullptr;
+  int* status_host = nullptr;
+  int* slot_seen = nullptr;
+  int check_mode = UT_CHECK_SYNC;
   // profiling
   bool profiling = false;
   std::vector<ProfEvent> prof;
@@ -100,6 +107,77 @@ int fail(ut_handle h, int code, const char* what, hipError_t e = hipSuccess) {
   } while (0)
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Every entry that allocates or launches runs on the handle's device whatever the caller's current device is,
+// and leaves the caller's current device as it found it.
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceScope(int dev) {      // dev < 0: stay on the caller's current device
+    if (dev < 0) return;
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) {
+      err = hipSetDevice(dev);
+      switched = err == hipSuccess;
+    }
+  }
+  ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
+#define ON_DEVICE_IF(h)                                        \
+  DeviceScope scope_((h) ? (h)->device : -1);                  \
+  if ((h) && scope_.err != hipSuccess) return fail(h, UT_E_HIP, "hipSetDevice", scope_.err)
+#define ON_DEVICE_OF(h)                 \
+  DeviceScope scope_((h)->device);      \
+  if (scope_.err != hipSuccess) return fail(h, UT_E_HIP, "hipSetDevice", scope_.err)
+
+// Status words for the stateless entry points (handle == NULL): one pair per device, created on first use.
+struct DevStatus { int* dev = nullptr; int* host = nullptr; };
+std::mutex g_status_mutex;
+DevStatus g_status[64];
+
+int stateless_status(int* device_out, DevStatus* out) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return fail(nullptr, UT_E_HIP, "hipGetDevice", e);
+  if (dev < 0 || dev >= 64) return fail(nullptr, UT_E_INVALID, "device index beyond 63");
+  std::lock_guard<std::mutex> lock(g_status_mutex);
+  DevStatus& st = g_status[dev];
+  if (!st.dev) {
+    void *d = nullptr, *hst = nullptr;
+    if ((e = hipMalloc(&d, 2 * sizeof(int))) != hipSuccess) return fail(nullptr, UT_E_HIP, "hipMalloc", e);
+    if ((e = hipHostMalloc(&hst, 2 * sizeof(int), hipHostMallocDefault)) != hipSuccess) {
+      (void)hipFree(d);
+      return fail(nullptr, UT_E_HIP, "hipHostMalloc", e);
+    }
+    if ((e = hipMemset(d, 0, 2 * sizeof(int))) != hipSuccess) return fail(nullptr, UT_E_HIP, "hipMemset", e);
+    st.dev = (int*)d; st.host = (int*)hst;
+  }
+  *device_out = dev;
+  *out = st;
+  return UT_OK;
+}
+
+const char* status_message(int bits) {
+  if (bits & ut::UT_BAD_SRC_INDEX) return "index check: src_index outside [0, n_src_images)";
+  if (bits & ut::UT_BAD_SAMPLE_RANGE) return "index check: sample_range rows must select 1 or 2 crops inside [0, n_crops]";
+  if (bits & ut::UT_BAD_MEMORY_IDX) return "index check: memory_idx outside [0, n_slots)";
+  if (bits & ut::UT_DUP_MEMORY_IDX) return "index check: memory_idx names one temporal slot twice";
+  if (bits & ut::UT_BAD_HAND_IDX) return "index check: hand_idx must be 0 (left) or 1 (right)";
+  return "index check: failed";
+}
+
+// Read the status words back (synchronises the stream), clear the sticky word when it holds an error.
+int read_status(ut_handle h, int* dev, int* host, hipStream_t s, int* sticky, int* call) {
+  HIPCHK(h, hipMemcpyAsync(host, dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  *sticky = host[0];
+  *call = host[1];
+  if (*sticky) HIPCHK(h, hipMemsetAsync(dev, 0, sizeof(int), s));
+  return UT_OK;
+}
 
 struct Cursor {
   const float* p;
@@ -268,9 +346,11 @@ int ensure_slots(ut_handle h, int slots, hipStream_t s) {
   if (slots <= h->slots_cap) return UT_OK;
   int cap = h->slots_cap ? h->slots_cap : 2;
   while (cap < slots) cap *= 2;
-  float *nm = nullptr, *ne = nullptr;
+  float *nm = nullptr, *ne = nullptr, *seen = nullptr;
   int rc;
-  if ((rc = dev_alloc(h, &nm, (size_t)cap * 36 * 18)) || (rc = dev_alloc(h, &ne, (size_t)cap * 16))) return rc;
+  if ((rc = dev_alloc(h, &nm, (size_t)cap * 36 * 18)) || (rc = dev_alloc(h, &ne, (size_t)cap * 16)) ||
+      (rc = dev_alloc(h, &seen, (size_t)cap)))
+    return rc;
   HIPCHK(h, hipMemsetAsync(nm, 0, (size_t)cap * 36 * 18 * sizeof(float), s));
   HIPCHK(h, hipMemsetAsync(ne, 0, (size_t)cap * 16 * sizeof(float), s));
   if (h->slots_cap) {
@@ -279,8 +359,9 @@ int ensure_slots(ut_handle h, int slots, hipStream_t s) {
     HIPCHK(h, hipStreamSynchronize(s));
     dev_free(h, h->mem);
     dev_free(h, h->prev_ext);
+    dev_free(h, h->slot_seen);
   }
-  h->mem = nm; h->prev_ext = ne; h->slots_cap = cap;
+  h->mem = nm; h->prev_ext = ne; h->slot_seen = (int*)seen; h->slots_cap = cap;
   return UT_OK;
 }
 
@@ -304,7 +385,7 @@ int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, fl
   c.k_total = cw.k_total; c.k_pad = cw.k_pad; c.cslice = cw.cslice;
   c.ksize = cw.ksize; c.stride = cw.stride; c.pad = cw.pad;
   c.relu = relu; c.out_nchw = nchw;
-  c.num_cu = h->num_cu; c.persist_limit = h->persist_limit; c.stagger = h->stagger;
+  c.device = h->device; c.num_cu = h->num_cu; c.persist_limit = h->persist_limit; c.stagger = h->stagger;
   if (h->counter_next >= kMaxCounters) {   // recycle: stream order puts the memset behind the earlier launches
     int rc0 = begin_call(h, s);
     if (rc0) return rc0;
@@ -350,8 +431,8 @@ const char* ut_last_error(ut_handle h) { return h ? h->err.c_str() : g_create_er
 int ut_create(int device, const float* blob, size_t n_floats, ut_handle* out) {
   if (!blob || !out) return fail(nullptr, UT_E_INVALID, "ut_create: null argument");
   if (n_floats != UT_WEIGHT_BLOB_FLOATS) return fail(nullptr, UT_E_WEIGHTS, "ut_create: weight blob has the wrong length");
-  hipError_t e = hipSetDevice(device);
-  if (e != hipSuccess) return fail(nullptr, UT_E_HIP, "hipSetDevice", e);
+  DeviceScope scope(device);          // the caller's current device is restored on return
+  if (scope.err != hipSuccess) return fail(nullptr, UT_E_HIP, "hipSetDevice", scope.err);
   ut_handle h = new ut_context();
   h->device = device;
   {
@@ -375,6 +456,10 @@ int ut_create(int device, const float* blob, size_t n_floats, ut_handle* out) {
     }
     if ((rc = upload(h, w, &h->stem_w)) || (rc = upload(h, b, &h->stem_b))) break;
     { float* cnt = nullptr; if ((rc = dev_alloc(h, &cnt, kMaxCounters))) break; h->counters = (unsigned*)cnt; }
+    { float* st = nullptr; if ((rc = dev_alloc(h, &st, 2))) break; h->status = (int*)st;
+      hipError_t e2 = hipMemset(h->status, 0, 2 * sizeof(int));
+      if (e2 == hipSuccess) e2 = hipHostMalloc((void**)&h->status_host, 2 * sizeof(int), hipHostMallocDefault);
+      if (e2 != hipSuccess) { rc = fail(h, UT_E_HIP, "status words", e2); break; } }
     // ResNet layers "2352", planes 32/64/128/256, strides 1/2/2/2 (lib/models/backbone_resnet.py:168-192)
     const int nb[4] = {2, 3, 5, 2}, planes[4] = {32, 64, 128, 256}, strides[4] = {1, 2, 2, 2};
     int cin = 32, bi = 0;
@@ -430,9 +515,10 @@ int ut_create(int device, const float* blob, size_t n_floats, ut_handle* out) {
 
 int ut_destroy(ut_handle h) {
   if (!h) return UT_OK;
-  (void)hipSetDevice(h->device);
+  DeviceScope scope(h->device);
   (void)hipDeviceSynchronize();
   for (void* p : h->allocs) (void)hipFree(p);
+  if (h->status_host) (void)hipHostFree(h->status_host);
   for (auto& pe : h->prof) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
   delete h;
   return UT_OK;
@@ -447,7 +533,7 @@ int ut_set_backbone_chunk(ut_handle h, int crops_per_pass) {
 
 int ut_reserve(ut_handle h, int max_crops, int max_samples, int max_slots) {
   if (!h) return UT_E_INVALID;
-  HIPCHK(h, hipSetDevice(h->device));
+  ON_DEVICE_OF(h);
   int rc;
   int c = max_crops < h->chunk ? max_crops : h->chunk;
   if (c > 0 && (rc = ensure_backbone_ws(h, c))) return rc;
@@ -461,13 +547,33 @@ int ut_reserve(ut_handle h, int max_crops, int max_samples, int max_slots) {
 int ut_warp_crops(ut_handle h, const uint8_t* src, int n_src_images, int src_h, int src_w, const double* cam_params,
                   const double* crop_params, const int32_t* src_index, int n_crops, int remap_mode, float* out,
                   void* stream) {
-  // stateless: h may be NULL
+  // stateless: h may be NULL (then the call runs on the caller's current device and always checks synchronously)
   if (n_crops == 0) return UT_OK;
   if (!src || !cam_params || !crop_params || !src_index || !out || n_crops < 0 || src_h <= 0 || src_w <= 0 ||
       n_src_images <= 0 || (remap_mode != UT_REMAP_CV2_FIXED && remap_mode != UT_REMAP_FLOAT))
     return fail(h, UT_E_INVALID, "ut_warp_crops: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  int *st_dev = nullptr, *st_host = nullptr, mode = UT_CHECK_SYNC, dev = 0;
+  if (h) { st_dev = h->status; st_host = h->status_host; mode = h->check_mode; dev = h->device; }
+  else {
+    DevStatus st;
+    int rc = stateless_status(&dev, &st);
+    if (rc) return rc;
+    st_dev = st.dev; st_host = st.host;
+  }
+  DeviceScope scope(dev);
+  if (scope.err != hipSuccess) return fail(h, UT_E_HIP, "hipSetDevice", scope.err);
   HIPCHK(h, ut::launch_warp(src, n_src_images, src_h, src_w, cam_params, crop_params, src_index, n_crops, remap_mode,
-                            out, (hipStream_t)stream));
+                            out, st_dev, s));
+  if (mode == UT_CHECK_SYNC) {
+    int sticky = 0, call = 0, rc = read_status(h, st_dev, st_host, s, &sticky, &call);
+    if (rc) return rc;
+    if (sticky & ut::UT_STATUS_ERRORS) {
+      char buf[160];
+      snprintf(buf, sizeof buf, "ut_warp_crops: %s", status_message(sticky));
+      return fail(h, UT_E_INVALID, buf);
+    }
+  }
   return UT_OK;
 }
 
@@ -475,6 +581,7 @@ int ut_backbone(ut_handle h, const float* crops, int n_crops, float* feat, void*
   if (!h) return UT_E_INVALID;
   if (n_crops == 0) return UT_OK;
   if (!crops || !feat || n_crops < 0) return fail(h, UT_E_INVALID, "ut_backbone: bad argument");
+  ON_DEVICE_OF(h);
   hipStream_t s = (hipStream_t)stream;
   int rc;
   const int chunk = n_crops < h->chunk ? n_crops : h->chunk;
@@ -533,16 +640,35 @@ int ut_fuse_temporal_regress(ut_handle h, const float* feat, const float* intrin
   } else {
     return fail(h, UT_E_INVALID, "ut_fuse_temporal_regress: unknown mode");
   }
+  ON_DEVICE_OF(h);
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if ((rc = ensure_head_ws(h, n_samples, n_skel))) return rc;
   if ((rc = ensure_slots(h, n_slots, s))) return rc;
-  if (n_slots > h->slots_used) h->slots_used = n_slots;
   if ((rc = begin_call(h, s))) return rc;
   ut::HeadArgs a{};
   a.feat = feat; a.intrinsics = intrinsics; a.extrinsics = extrinsics; a.sample_range = sample_range;
   a.memory_idx = memory_idx; a.use_memory = use_memory; a.hand_idx = hand_idx; a.n_samples = n_samples;
+  a.n_crops = n_crops; a.n_slots = n_slots;
   a.mem = h->mem; a.prev_ext = h->prev_ext;
+  a.status = h->status; a.slot_seen = h->slot_seen;
+  a.call_error_mask = mode == UT_MODE_UNKNOWN_SKELETON ? ut::UT_SINGLE_VIEW : 0;
+  // index checks (stream ordered, in front of everything that indexes with the descriptors)
+  HIPCHK(h, hipMemsetAsync(h->status + 1, 0, sizeof(int), s));
+  HIPCHK(h, hipMemsetAsync(h->slot_seen, 0, (size_t)n_slots * sizeof(int), s));
+  HIPCHK(h, ut::launch_validate_desc(a, s));
+  if (h->check_mode == UT_CHECK_SYNC) {
+    int sticky = 0, call = 0;
+    if ((rc = read_status(h, h->status, h->status_host, s, &sticky, &call))) return rc;
+    if (sticky & ut::UT_STATUS_ERRORS) {
+      char buf[160];
+      snprintf(buf, sizeof buf, "ut_fuse_temporal_regress: %s", status_message(sticky));
+      return fail(h, UT_E_INVALID, buf);
+    }
+    if (call & a.call_error_mask)   // lib/models/umetrack_model.py:224-229
+      return fail(h, UT_E_UNSUPPORTED, "Unsupported: found single-view samples when calibration scale");
+  }
+  if (n_slots > h->slots_used) h->slots_used = n_slots;
   const ut::HeadBuffers& b = h->hb;
   const int S = n_samples;
   HIPCHK(h, ut::launch_ftl_in(a, b, s));
@@ -566,7 +692,7 @@ int ut_fuse_temporal_regress(ut_handle h, const float* feat, const float* intrin
 
 int ut_reset_memory(ut_handle h) {
   if (!h) return UT_E_INVALID;
-  HIPCHK(h, hipSetDevice(h->device));
+  ON_DEVICE_OF(h);
   HIPCHK(h, hipDeviceSynchronize());
   if (h->slots_cap) {
     HIPCHK(h, hipMemset(h->mem, 0, (size_t)h->slots_cap * 36 * 18 * sizeof(float)));
@@ -578,6 +704,7 @@ int ut_reset_memory(ut_handle h) {
 
 int ut_get_memory(ut_handle h, float* mem, float* prev_ext, int max_slots, void* stream) {
   if (!h) return UT_E_INVALID;
+  ON_DEVICE_OF(h);
   int n = h->slots_used < max_slots ? h->slots_used : max_slots;
   if (n > 0) {
     if (!mem || !prev_ext) return fail(h, UT_E_INVALID, "ut_get_memory: null output");
@@ -595,6 +722,7 @@ int ut_fk(ut_handle h, const float* hand_model, int n_models, const float* joint
   if (!hand_model || !joint_angles || !wrist_xf || !out || n < 0 || (n_models != 1 && n_models != n) ||
       ja_stride < 22 || xf_stride < 16)
     return fail(h, UT_E_INVALID, "ut_fk: bad argument");
+  ON_DEVICE_IF(h);
   HIPCHK(h, ut::launch_fk(hand_model, n_models, joint_angles, ja_stride, wrist_xf, xf_stride, mirror, t_scale, n, out,
                           (hipStream_t)stream));
   return UT_OK;
@@ -611,6 +739,7 @@ int ut_gen_crop_cameras(ut_handle h, const double* cam_params, const double* cam
       !hand_idx || !crop_params || !intrinsics || !extrinsics || !cam_index || !n_views || !status || n < 0 ||
       (n_models != 1 && n_models != n) || n_cams <= 0 || max_views <= 0 || src_w <= 0 || src_h <= 0 || crop_size <= 1)
     return fail(h, UT_E_INVALID, "ut_gen_crop_cameras: bad argument");
+  ON_DEVICE_IF(h);
   ut::CropGenArgs g{};
   g.cam_params = cam_params; g.camera_angles = camera_angles; g.hand_model = hand_model; g.joint_limits = joint_limits;
   g.joint_angles = joint_angles; g.wrist_xf = wrist_xf; g.frame_idx = frame_idx; g.hand_idx = hand_idx;
@@ -630,6 +759,7 @@ int ut_gen_crop_matrices(ut_handle h, const float* orig_extrinsics, const float*
   if (!orig_extrinsics || !orig_intrinsics || !crop_points || !hand_idx || !extrinsics_xf || !new_intrinsics ||
       !resample_xf || !status || n_frames < 0 || n_views < 0 || n_pts <= 0 || crop_size <= 1)
     return fail(h, UT_E_INVALID, "ut_gen_crop_matrices: bad argument");
+  ON_DEVICE_IF(h);
   ut::CropMatArgs g{};
   g.orig_extrinsics = orig_extrinsics; g.orig_intrinsics = orig_intrinsics; g.crop_points = crop_points;
   g.hand_idx = hand_idx; g.n_frames = n_frames; g.n_views = n_views; g.n_pts = n_pts; g.crop_size = crop_size;
@@ -644,6 +774,7 @@ int ut_resample_homography(ut_handle h, const void* src, int src_is_f32, int n, 
   if (n == 0) return UT_OK;
   if (!src || !resample_xf || !out || n < 0 || src_h < 2 || src_w < 2 || out_h <= 0 || out_w <= 0)
     return fail(h, UT_E_INVALID, "ut_resample_homography: bad argument");
+  ON_DEVICE_IF(h);
   HIPCHK(h, ut::launch_resample_homography(src, src_is_f32, n, src_h, src_w, resample_xf, out_h, out_w, out,
                                            (hipStream_t)stream));
   return UT_OK;
@@ -655,8 +786,28 @@ int ut_keypoint_metrics(ut_handle h, const float* gt, const float* tracked, cons
   if (!gt || !tracked || !valid || !err || n_hands < 0 || n_frames < 0 ||
       (n_frames >= 3 && (!acc || !gt_acc || !valid_acc)))
     return fail(h, UT_E_INVALID, "ut_keypoint_metrics: bad argument");
+  ON_DEVICE_IF(h);
   HIPCHK(h, ut::launch_keypoint_metrics(gt, tracked, valid, n_hands, n_frames, err, acc, gt_acc, valid_acc,
                                         (hipStream_t)stream));
+  return UT_OK;
+}
+
+int ut_set_index_checks(ut_handle h, int mode) {
+  if (!h || (mode != UT_CHECK_SYNC && mode != UT_CHECK_DEFERRED)) return fail(h, UT_E_INVALID, "ut_set_index_checks: bad argument");
+  h->check_mode = mode;
+  return UT_OK;
+}
+
+int ut_poll_status(ut_handle h, void* stream) {
+  if (!h) return UT_E_INVALID;
+  ON_DEVICE_OF(h);
+  int sticky = 0, call = 0, rc = read_status(h, h->status, h->status_host, (hipStream_t)stream, &sticky, &call);
+  if (rc) return rc;
+  if (sticky & ut::UT_STATUS_ERRORS) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "reported late (deferred checks): %s", status_message(sticky));
+    return fail(h, UT_E_INVALID, buf);
+  }
   return UT_OK;
 }
 
@@ -671,6 +822,7 @@ int ut_profile_begin(ut_handle h, void* stream) {
 
 int ut_profile_end(ut_handle h, void* stream, double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total) {
   if (!h) return UT_E_INVALID;
+  ON_DEVICE_OF(h);
   h->profiling = false;
   HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
   double ms = 0, fl = 0;

@@ -27,6 +27,7 @@ struct ConvLaunch {
   int ksize, stride, pad;
   int relu;
   int out_nchw;
+  int device;          // HIP device the launch goes to (the dynamic-LDS attribute is set once per device)
   int num_cu;          // compute units of the device (persistent grid sizing)
   int persist_limit;   // > 0: cap on the persistent grid (debug / tuning)
   unsigned* tile_counter;   // device word, zero before the launch: dynamic tile queue of the persistent grid
@@ -61,6 +62,17 @@ struct HeadBuffers {
   float* xf;        // [S,40] per-sample transforms: A0(12) A1(12) s0(1) rel(12) flags
 };
 
+// Bits of the sticky device status word written by the index checks (ut_api.hip turns them into UT_E_INVALID).
+enum : int {
+  UT_BAD_SAMPLE_RANGE = 1,   // a sample_range row is not 1 or 2 crops inside [0, n_crops]
+  UT_BAD_MEMORY_IDX = 2,     // memory_idx outside [0, n_slots)
+  UT_DUP_MEMORY_IDX = 4,     // two samples of one call name the same temporal slot
+  UT_BAD_HAND_IDX = 8,       // hand_idx not 0 / 1
+  UT_SINGLE_VIEW = 16,       // informational: at least one one-view sample (an error only in unknown-skeleton mode)
+  UT_BAD_SRC_INDEX = 32,     // ut_warp_crops: src_index outside [0, n_src_images)
+};
+constexpr int UT_STATUS_ERRORS = UT_BAD_SAMPLE_RANGE | UT_BAD_MEMORY_IDX | UT_DUP_MEMORY_IDX | UT_BAD_HAND_IDX | UT_BAD_SRC_INDEX;
+
 struct HeadArgs {
   const float* feat;        // [N,72,36] NCHW
   const float* intrinsics;  // [N,3,3]
@@ -70,9 +82,20 @@ struct HeadArgs {
   const uint8_t* use_memory;
   const int64_t* hand_idx;
   int n_samples;
+  int n_crops;
+  int n_slots;
   float* mem;               // [slots,36,18] NHWC temporal memory
   float* prev_ext;          // [slots,16]
+  int* status;              // device words: [0] sticky error bits (UT_* above), [1] bits of THIS call (zero on entry).
+                            // Kernels that index with the descriptors return when status[0] has an error bit or
+                            // status[1] a bit of call_error_mask: nothing is read or written out of range and the
+                            // temporal state stays as it was
+  int call_error_mask;      // UT_SINGLE_VIEW in unknown-skeleton mode (lib/models/umetrack_model.py:224-229), else 0
+  int* slot_seen;           // [n_slots] scratch of the duplicate check, zero on entry
 };
+
+// One pass over the frame descriptors before anything indexes with them (stream ordered).
+hipError_t launch_validate_desc(const HeadArgs& a, hipStream_t s);
 
 hipError_t launch_ftl_in(const HeadArgs& a, const HeadBuffers& b, hipStream_t s);
 hipError_t launch_ftl_out_temporal_in(const HeadArgs& a, const HeadBuffers& b, hipStream_t s);
@@ -134,8 +157,9 @@ hipError_t launch_keypoint_metrics(const float* gt, const float* tracked, const 
 
 hipError_t launch_mem_export(const float* mem /*[slots,36,18]*/, float* out /*[slots,18,36]*/, int slots, hipStream_t s);
 
+// status: device word; a crop whose src_index is outside [0, n_src) is written as zeros and sets UT_BAD_SRC_INDEX
 hipError_t launch_warp(const uint8_t* src, int n_src, int src_h, int src_w, const double* cam,
                        const double* crop, const int32_t* src_index, int n_crops, int mode, float* out,
-                       hipStream_t s);
+                       int* status, hipStream_t s);
 
 }  // namespace ut

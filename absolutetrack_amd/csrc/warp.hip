@@ -19,12 +19,17 @@ __device__ inline int tap(const uint8_t* img, int h, int w, int x, int y) {
 __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ src, int src_h, int src_w,
                                                    const double* __restrict__ cam,
                                                    const double* __restrict__ crop,
-                                                   const int32_t* __restrict__ src_index, int mode,
-                                                   float* __restrict__ out) {
+                                                   const int32_t* __restrict__ src_index, int n_src, int mode,
+                                                   float* __restrict__ out, int* __restrict__ status) {
   const int ci = blockIdx.y;
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= CROP_PX) return;
   const int si = src_index[ci];
+  if (si < 0 || si >= n_src) {      // the reference would raise IndexError on views[cam_idx] (lib/tracker/tracker.py:330)
+    out[(size_t)ci * CROP_PX + pix] = 0.f;
+    if (pix == 0) atomicOr(status, UT_BAD_SRC_INDEX);
+    return;
+  }
   const double* cp = crop + (size_t)ci * 24;
   const double* sp = cam + (size_t)si * 32;
   const int px = pix % 96, py = pix / 96;
@@ -90,12 +95,11 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ s
 }
 
 hipError_t launch_warp(const uint8_t* src, int n_src, int src_h, int src_w, const double* cam, const double* crop,
-                       const int32_t* src_index, int n_crops, int mode, float* out, hipStream_t s) {
-  (void)n_src;
+                       const int32_t* src_index, int n_crops, int mode, float* out, int* status, hipStream_t s) {
   for (int done = 0; done < n_crops;) {
     int cnt = n_crops - done < 32768 ? n_crops - done : 32768;
     hipLaunchKernelGGL(warp_kernel, dim3(CROP_PX / 256, cnt), dim3(256), 0, s, src, src_h, src_w, cam,
-                       crop + (size_t)done * 24, src_index + done, mode, out + (size_t)done * CROP_PX);
+                       crop + (size_t)done * 24, src_index + done, n_src, mode, out + (size_t)done * CROP_PX, status);
     done += cnt;
   }
   return hipGetLastError();

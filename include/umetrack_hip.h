@@ -12,7 +12,18 @@
  *    synchronises the device except ut_create/ut_reserve/ut_destroy.
  *  - return value: 0 = ok, negative = error (UT_E_*); ut_last_error() gives the message.
  *  - a handle is bound to one device and is not thread-safe; distinct handles are independent
- *    (the reference runs one model per process, run_eval_known_skeleton.py:117-119).
+ *    (the reference runs one model per process, run_eval_known_skeleton.py:117-119).  Every entry
+ *    that takes a handle runs on the handle's device whatever the caller's current device is and
+ *    restores the caller's; entries called with handle == NULL run on the current device.
+ *  - index tensors are checked ON THE DEVICE before anything indexes with them: src_index of
+ *    ut_warp_crops, sample_range / memory_idx / hand_idx of ut_fuse_temporal_regress (the reference
+ *    raises IndexError / asserts on these in Python: lib/tracker/tracker.py:330,
+ *    lib/models/temporal.py:101-137, lib/models/umetrack_model.py:149-166,224-229).  A bad entry
+ *    never leads to an out-of-range access and leaves the temporal state untouched.  By default
+ *    (UT_CHECK_SYNC) the call reads the verdict back - one stream synchronisation - and returns
+ *    UT_E_INVALID; with ut_set_index_checks(h, UT_CHECK_DEFERRED) nothing synchronises (needed inside
+ *    hipGraph capture and for run-ahead launching), the affected work is skipped on the device and
+ *    the error is reported by the next ut_poll_status.
  */
 #ifndef UMETRACK_HIP_H
 #define UMETRACK_HIP_H
@@ -35,6 +46,7 @@ enum {
 };
 
 enum { UT_MODE_KNOWN_SKELETON = 0, UT_MODE_UNKNOWN_SKELETON = 1 };
+enum { UT_CHECK_SYNC = 0, UT_CHECK_DEFERRED = 1 };
 enum { UT_REMAP_CV2_FIXED = 0, UT_REMAP_FLOAT = 1 };
 
 #define UT_CROP 96
@@ -57,6 +69,12 @@ int ut_create(int device, const float* weights_blob, size_t n_floats, ut_handle*
 int ut_destroy(ut_handle h);
 const char* ut_last_error(ut_handle h);   /* h may be NULL: error of the last failed ut_create */
 
+/* UT_CHECK_SYNC (default) or UT_CHECK_DEFERRED, see "index tensors" above. */
+int ut_set_index_checks(ut_handle h, int mode);
+/* Synchronises `stream`, returns UT_E_INVALID (and clears the flag) if an index check has failed in any
+ * call on this handle since the last poll, else UT_OK. */
+int ut_poll_status(ut_handle h, void* stream);
+
 /* Pre-size the activation workspace / temporal state so that later calls never allocate
  * (needed before capturing calls into a hipGraph). */
 int ut_reserve(ut_handle h, int max_crops, int max_samples, int max_slots);
@@ -73,7 +91,7 @@ int ut_set_backbone_chunk(ut_handle h, int crops_per_pass);
  *               (lib/common/camera.py:61-75,320-329)
  *  src_index    i32 [n_crops] which source image each crop samples
  *  out          f32 [n_crops, 96, 96] in [0,1]
- *  (stateless: h may be NULL)
+ *  (stateless: h may be NULL; then the index check is always synchronous)
  *  remap_mode   UT_REMAP_CV2_FIXED: OpenCV's 8-bit INTER_LINEAR arithmetic (coordinates to 1/32
  *               px, 15-bit weights, rounded u8) then /255;  UT_REMAP_FLOAT: exact float bilinear. */
 int ut_warp_crops(ut_handle h, const uint8_t* src, int n_src_images, int src_h, int src_w,
@@ -91,11 +109,12 @@ int ut_backbone(ut_handle h, const float* crops, int n_crops, float* feat, void*
  * skeleton encoder, pose regressor, decoders (lib/models/regressor.py:76-121,163-186),
  * Procrustes (lib/models/model_utils.py:17-54) and the world transform (:77-90).
  *  feat [n_crops,72,6,6]; intrinsics [n_crops,3,3]; extrinsics [n_crops,4,4];
- *  sample_range i64 [n_samples,2] (1 or 2 views per sample); memory_idx i64 [n_samples]
- *  (distinct slots, all < n_slots); use_memory u8 [n_samples]; hand_idx i64 [n_samples];
+ *  sample_range i64 [n_samples,2] (1 or 2 views per sample, inside [0,n_crops]); memory_idx i64
+ *  [n_samples] (distinct slots, all in [0,n_slots)); use_memory u8 [n_samples]; hand_idx i64
+ *  [n_samples] in {0,1} - all checked on the device, UT_E_INVALID otherwise;
  *  skel f32 [n_skel,2,22,3] = (joint_rotation_axes, joint_rest_positions[m]) with n_skel in
- *  {1, n_samples}, NULL in UT_MODE_UNKNOWN_SKELETON (single-view samples are then rejected on
- *  the host when `all_multiview` is 0);
+ *  {1, n_samples}, NULL in UT_MODE_UNKNOWN_SKELETON (single-view samples are then rejected with
+ *  UT_E_UNSUPPORTED: on the host when `all_multiview` is 0, else by the per-sample device check);
  *  n_slots = max(memory_idx)+1 as computed by the caller (lib/models/temporal.py:102);
  *  out_pose f32 [n_samples,60]; out_raw (optional, may be NULL) f32 [n_samples,64] regressor
  *  output before decoding. */

@@ -249,6 +249,20 @@ def export_torch_data():
         out[key + "images"] = np.asarray(img, np.float32)
         out[key + "extrinsics_xf"] = ext
         out[key + "intrinsics"] = intr
+        # The same reference functions on the same values held as float64: the look-at chain (six LAPACK inverses,
+        # several GEMMs) then runs in double precision and is rounded to float32 once, at the stores into the
+        # function's float32 result arrays.  The float32 run above differs from this one by the rounding of OpenBLAS's
+        # sgesv / sgemm kernels, whose operation order depends on the kernel DYNAMIC_ARCH picks for the host CPU.
+        res64 = np.empty((n_frames, 2, 4, 4), np.float32)
+        ext64 = np.empty((n_frames, 2, 4, 4), np.float32)
+        intr64 = np.empty((n_frames, 2, 3, 3), np.float32)
+        for f in range(n_frames):
+            ext64[f], intr64[f], res64[f] = rdt._gen_crop_matrices(
+                c["extrinsics"][f].astype(np.float64), c["intrinsics"][f].astype(np.float64),
+                c["crop_points"][f].astype(np.float64), hand == 1, (96, 96))
+        out[key + "resample_xf_f64chain"] = res64
+        out[key + "extrinsics_xf_f64chain"] = ext64
+        out[key + "intrinsics_f64chain"] = intr64
     np.savez_compressed(os.path.join(GOLD, "torch_data.npz"), **out)
 
 

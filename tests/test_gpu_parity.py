@@ -216,7 +216,7 @@ def test_fk_multi_bone_blend_and_duplicate_bone_entries(engine, golden_dir):
     w = rng.uniform(0.1, 1.0, (n, 21, 3)).astype(np.float32)
     idx = rng.integers(0, 17, (n, 21, 3)).astype(np.int64)
     w[:, ::3, 2] = 0                      # two bones only
-    w[:, 1::5, 0] = 0                     # a zero in front of non-zeros
+    w[:, 1::6, 0] = 0                     # a zero in front of non-zeros
     idx[:, 2::4, 2] = idx[:, 2::4, 0]     # duplicate bone, both weights non-zero: the later entry wins
     idx[:, 3::7, 1] = idx[:, 3::7, 2]
     w /= w.sum(-1, keepdims=True)
@@ -292,6 +292,136 @@ def test_warp_matches_oracle(engine, mode):
         assert diff.max() <= 8.0 / 255.0
     else:
         assert diff.max() < 1e-4
+
+
+def _head_inputs(engine, n_samples=3, seed=2):
+    n = 2 * n_samples
+    g = torch.Generator(device=DEV)
+    g.manual_seed(seed)
+    feat = engine.backbone(_dev(synth.synthetic_crops(n, seed=seed)))
+    k = torch.eye(3, device=DEV).repeat(n, 1, 1)
+    k[:, 0, 0] = k[:, 1, 1] = 100 + 60 * torch.rand(n, device=DEV, generator=g)
+    k[:, 0, 2] = k[:, 1, 2] = 47.5
+    x = torch.eye(4, device=DEV).repeat(n, 1, 1)
+    x[:, :3, 3] = torch.rand(n, 3, device=DEV, generator=g) * 0.2
+    sr = torch.arange(0, n, 2, device=DEV)[:, None] + torch.tensor([0, 2], device=DEV)
+    hm = scenarios.hand_model_mm()
+    skel = _dev(np.stack([hm["joint_rotation_axes"], hm["joint_rest_positions"] * np.float32(0.001)])[None].astype(np.float32))
+    return dict(feat=feat, k=k, x=x, sr=sr, mem=torch.arange(n_samples, device=DEV), use=torch.zeros(n_samples, dtype=torch.bool, device=DEV),
+                hand=(torch.arange(n_samples, device=DEV) % 2), skel=skel, s=n_samples)
+
+
+def _head_call(engine, d, mode=_native.UT_MODE_KNOWN, **over):
+    a = dict(d, **over)
+    return engine.fuse_temporal_regress(a["feat"], a["k"], a["x"], a["sr"], a["mem"], a["use"], a["hand"],
+                                        over.get("n_slots", a["s"]), over.get("all_multiview", True),
+                                        a["skel"] if mode == _native.UT_MODE_KNOWN else None, mode)[0].clone()
+
+
+def test_index_checks_reject_bad_descriptors(engine):
+    """What the reference raises IndexError / AssertionError on in Python (lib/tracker/tracker.py:330,
+    lib/models/temporal.py:101-137, lib/models/umetrack_model.py:149-166,224-229) comes back as UT_E_INVALID /
+    UT_E_UNSUPPORTED from the device-side checks: nothing is read or written out of range and the temporal state is
+    the same afterwards."""
+    engine.reset_memory()
+    d = _head_inputs(engine)
+    s = d["s"]
+    good = _head_call(engine, d)
+    mem0, ext0 = [t.clone() for t in engine.get_memory()]
+    t = lambda v: torch.tensor(v, device=DEV)
+    bad_cases = {
+        "range width 3": dict(sr=t([[0, 3], [2, 4], [4, 6]])),
+        "range width 0": dict(sr=t([[0, 2], [3, 3], [4, 6]])),
+        "range negative": dict(sr=t([[-1, 1], [2, 4], [4, 6]])),
+        "range past n_crops": dict(sr=t([[0, 2], [2, 4], [5, 7]])),
+        "slot == n_slots": dict(mem=t([0, 1, 3])),
+        "slot negative": dict(mem=t([0, -1, 2])),
+        "slot far out": dict(mem=t([0, 1, 1 << 40])),
+        "duplicate slot": dict(mem=t([0, 1, 1])),
+        "hand 2": dict(hand=t([0, 1, 2])),
+        "hand -1": dict(hand=t([-1, 1, 0])),
+    }
+    for name, over in bad_cases.items():
+        with pytest.raises(IndexError, match="index check"):
+            _head_call(engine, d, **over)
+        mem1, ext1 = engine.get_memory()
+        assert torch.equal(mem1, mem0) and torch.equal(ext1, ext0), name       # state untouched
+    # unknown-skeleton mode: a one-view sample hidden behind n_crops == 2 * n_samples is found per sample
+    with pytest.raises(AssertionError, match="single-view"):
+        _head_call(engine, d, _native.UT_MODE_UNKNOWN, sr=t([[0, 1], [1, 3], [4, 6]]))
+    with pytest.raises(AssertionError, match="single-view"):
+        _head_call(engine, d, _native.UT_MODE_UNKNOWN, all_multiview=False)
+    # ... and is fine with the known skeleton (the single-view branch)
+    assert torch.isfinite(_head_call(engine, d, sr=t([[0, 1], [1, 3], [4, 6]]))).all()
+    engine.reset_memory()
+    assert torch.equal(_head_call(engine, d), good)
+    # resampler: src_index outside the source stack
+    src = torch.zeros(2, 480, 636, dtype=torch.uint8, device=DEV)
+    cam = torch.zeros(2, 32, dtype=torch.float64, device=DEV)
+    cam[:, 0:4] = torch.tensor([240.0, 240.0, 317.5, 239.5], dtype=torch.float64)
+    cam[:, 12] = cam[:, 16] = cam[:, 20] = 1
+    crop = torch.zeros(3, 24, dtype=torch.float64, device=DEV)
+    crop[:, 0:4] = torch.tensor([240.0, 240.0, 47.5, 47.5], dtype=torch.float64)
+    crop[:, 4] = crop[:, 8] = crop[:, 12] = 1
+    for idx in ([0, 2, 1], [0, -1, 1], [1 << 30, 0, 0]):
+        with pytest.raises(IndexError, match="src_index"):
+            engine.warp_crops(src, cam, crop, torch.tensor(idx, dtype=torch.int32, device=DEV))
+    assert engine.warp_crops(src, cam, crop, torch.tensor([0, 1, 1], dtype=torch.int32, device=DEV)).shape == (3, 96, 96)
+    # stateless entry (no handle): always synchronous
+    with pytest.raises(RuntimeError, match="src_index"):
+        rc = engine.lib.ut_warp_crops(None, _native._ptr(src), 2, 480, 636, _native._ptr(cam), _native._ptr(crop),
+                                      _native._ptr(torch.tensor([0, 5, 1], dtype=torch.int32, device=DEV)), 3, 0,
+                                      _native._ptr(torch.empty(3, 96, 96, device=DEV)), _native._stream(torch.device(DEV)))
+        if rc:
+            raise RuntimeError(engine.lib.ut_last_error(None).decode())
+
+
+def test_deferred_index_checks(engine):
+    """UT_CHECK_DEFERRED: the call itself does not synchronise or raise; the bad call's work is skipped on the device
+    (state and the rest of the batch untouched), ut_poll_status reports it once, later calls run normally."""
+    engine.reset_memory()
+    d = _head_inputs(engine)
+    good = _head_call(engine, d)
+    mem0, ext0 = [t.clone() for t in engine.get_memory()]
+    engine.set_index_checks(deferred=True)
+    try:
+        engine.poll_status()                                  # clean
+        _head_call(engine, d, mem=torch.tensor([0, 1, 7], device=DEV))
+        _head_call(engine, d)                                  # still flagged: skipped as well
+        mem1, ext1 = engine.get_memory()
+        assert torch.equal(mem1, mem0) and torch.equal(ext1, ext0)
+        with pytest.raises(IndexError, match="memory_idx"):
+            engine.poll_status()
+        engine.poll_status()                                  # reported once
+        engine.reset_memory()
+        assert torch.equal(_head_call(engine, d), good)
+        engine.poll_status()
+    finally:
+        engine.set_index_checks(deferred=False)
+
+
+def test_two_handles_on_one_device_are_independent(engine):
+    """A second handle in the same process (the dynamic-LDS attribute of the conv kernels is kept per device, temporal
+    state and workspace per handle); calls with another current stream / interleaved order give identical results."""
+    other = _native.HipEngine(synth.synthetic_state_dict(0), DEV)
+    try:
+        crops = _dev(synth.synthetic_crops(6, seed=12))
+        a = engine.backbone(crops)
+        b = other.backbone(crops)
+        assert torch.equal(a, b)
+        d = _head_inputs(engine)
+        engine.reset_memory()
+        other.reset_memory()
+        p1 = _head_call(engine, d)
+        q1 = _head_call(other, d)
+        p2 = _head_call(engine, d, use=torch.ones(3, dtype=torch.bool, device=DEV))     # uses engine's own memory
+        assert torch.equal(p1, q1) and not torch.equal(p2, p1)
+        assert other.get_memory()[0].shape[0] == 3
+        q2 = _head_call(other, d, use=torch.ones(3, dtype=torch.bool, device=DEV))
+        assert torch.equal(p2, q2)
+    finally:
+        other.close()
+    assert torch.equal(engine.backbone(crops), a)           # the first handle outlives the second
 
 
 def test_alternative_kernel_paths_agree():
