@@ -13,8 +13,7 @@
 // pixels, plain rows for the weights; out-of-image taps and rows beyond M get an out-of-range buffer offset and
 // arrive as zeros, so the load path has no branches.  LDS rows are 128 B, unpadded, their 16-byte chunks
 // XOR-swizzled by (row >> 1) & 7 on the SOURCE side (which chunk a lane fetches), which makes the ds_read_b128
-// fragment reads conflict free under gfx950's 16-lane read groups.  Two stages, one barrier per chunk.  (The
-// register-staged variant DMA = false, rows padded to 36 floats, is kept for comparison: UT_CONV_DMA.)
+// fragment reads conflict free under gfx950's 16-lane read groups.  Two stages, one barrier per chunk.
 // Lane l of a wave holds row (l&31) of the fragment and k-half (l>>5); the 4 floats of a b128 read feed
 // 4 consecutive MFMAs (the k order inside the 8-run is permuted identically for A and B).
 //
@@ -32,8 +31,6 @@
 // bookkeeping of the chunk loop wave-uniform: it runs on the scalar unit and the loop body has no branch.
 // Tile shapes: 128x128 (cout > 64), 128x64 (cout <= 64, three workgroups per CU), 64x128 for launches with few
 // tiles (projection and head: 74 k pixels); layer1 (3x3, 32 -> 32) runs in conv_patch.hip instead.
-#include <stdlib.h>
-
 #include <atomic>
 
 #include "ut_kernels.h"
@@ -45,12 +42,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) float lds_f32;
 
 constexpr int BK = 32;
-// LDS row stride in floats.  Register staging: rows padded to 36 floats (144 B = 9 x 16 B) make the b128
-// fragment reads conflict free.  LDS-DMA staging (buffer_load ... lds) writes 64 lanes x 16 B = 8 whole rows
-// linearly, so rows are unpadded (32 floats) and the 16-byte chunks of a row are XOR-swizzled instead:
+// LDS row stride in floats.  LDS-DMA staging (buffer_load ... lds) writes 64 lanes x 16 B = 8 whole rows
+// linearly, so rows are unpadded (32 floats) and the 16-byte chunks of a row are XOR-swizzled:
 // chunk c of row r lives at position c ^ ((r >> 1) & 7).  The permutation is applied on the SOURCE side
 // (which global chunk a lane fetches); 16-lane read groups then hit 16 distinct 16-byte bank slots.
-template <bool DMA> constexpr int lds_row() { return DMA ? BK : BK + 4; }
+constexpr int LDS_ROW = BK;
 
 // One LDS-DMA piece: 64 lanes x 16 bytes from a buffer (per-lane byte offset, out-of-range -> zeros) straight
 // into LDS at lds_addr + lane*16.  Inline asm on purpose: with the builtin hipcc treats the pending LDS write
@@ -86,20 +82,16 @@ __device__ __forceinline__ int fast_div(int n, int d, float inv_d) {
   return q;
 }
 
-template <int BM, int BN, int WR, int WC, bool DMA, bool NCHW = false, bool C32 = false>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int tiles_n, int n_tiles) {
+template <int BM, int BN, int WR, int WC, bool NCHW = false, bool C32 = false>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int tiles_n, int n_tiles, int stagger) {
   static_assert(WR * WC == 4, "4 waves per workgroup");
   constexpr int MI = BM / WR / 32;   // 32x32 accumulator tiles per wave along M
   constexpr int NI = BN / WC / 32;   // ... along N
   constexpr int AP = BM / 32;        // 16-byte loads per thread per chunk for the A tile
   constexpr int BP = BN / 32;
-  constexpr int LDS_ROW = lds_row<DMA>();
   constexpr int STAGE = (BM + BN) * LDS_ROW;
   constexpr unsigned OOB = 0xFFFFFF00u;
-#ifndef UT_FINE_MASK
-#define UT_FINE_MASK 6          /* bit per MI*NI value (1, 2, 4): the 128x128 and 128x64 shapes */
-#endif
-  constexpr bool FINE = ((UT_FINE_MASK >> (MI * NI == 4 ? 2 : MI * NI == 2 ? 1 : 0)) & 1) && AP + BP <= 12;
+  static_assert(AP + BP <= 8, "the chunk loop places one LDS-DMA piece per MFMA step of its first two groups");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -110,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
   const int g = tid & 7;        // 16-byte position inside the staged LDS row this thread fills
   const int r0 = tid >> 3;      // first tile row this thread stages (then +32 per pass)
   // which 4-float group of the 32-wide k chunk lands there ((r0 + 32*i) >> 1 & 7 is the same for every pass i)
-  const int gk = DMA ? (g ^ ((r0 >> 1) & 7)) : g;
+  const int gk = g ^ ((r0 >> 1) & 7);
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // provably uniform: LDS-DMA base, M0
   const int fr = lane & 31;     // fragment row (A/B) == accumulator column
   const int fh = lane >> 5;     // k half (A/B) == accumulator row offset 4*fh
@@ -122,10 +114,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
   const int n_chunks = p.k_pad / BK;
   const unsigned b_row_step = (unsigned)(32 * p.k_pad * 4);
 
-  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.in), 0, (int)((size_t)p.n_img * p.H * p.W * p.cin * sizeof(float)), 0x00020000);
-  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.w), 0, (int)((size_t)p.cout_pad * p.k_pad * sizeof(float)), 0x00020000);
   // with no residual the descriptor is empty and every load returns 0
   const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.res ? p.res : p.bias), 0, p.res ? (int)((size_t)M * p.cout_store * sizeof(float)) : 0,
@@ -152,22 +140,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
   int a_pix[AP], a_iy[AP], a_ix[AP];
   unsigned b_off;
   int tap, ch, ch_base;
-  u32x4 a_reg[AP], b_reg[BP];
   // bias and residual of the tile being fetched: requested a tile ahead, combined only when that tile starts
   // (arithmetic at request time would make the compiler wait for the loads in front of the MFMAs)
   u32x4 res_raw[MI][NI][4];
   float4 bias_raw[NI][4];
 
-#ifdef UT_DIAG_NO_A   /* timing-only ablations (tools/diag) */
-#define UT_DIAG_A(x) asm volatile("" ::"v"(off))
-#else
-#define UT_DIAG_A(x) x
-#endif
-#ifdef UT_DIAG_NO_B
-#define UT_DIAG_B(x)
-#else
-#define UT_DIAG_B(x) x
-#endif
 #define UT_SETUP(TILE)                                                                               \
   {                                                                                                  \
     const int tm_ = (TILE) / tiles_n, tn_ = (TILE) - tm_ * tiles_n;                                  \
@@ -189,72 +166,37 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     tap = 0; ch = C32 ? 0 : 4 * gk; ch_base = 0;                                                     \
   }
 
-  // The AP+BP 16-byte loads of a chunk are issued in three parts, one in front of each of the first three
-  // MFMA groups, instead of in one burst behind the barrier: all waves of a workgroup leave the barrier
-  // together, and a burst of 8 loads x 4 waves backs up the address path so that the last wave cannot start
-  // its MFMAs (instructions issue in order) until its loads have been accepted.
-#define UT_FETCH_PART(PART, DSTBUF)                                                                  \
+  // Prologue only: all AP+BP pieces of a chunk in one burst (the steady state places them one per MFMA step).
+#define UT_FETCH(DSTBUF)                                                                             \
   {                                                                                                  \
     int dy = 0, dx = 0;                                                                              \
     if (p.ksize == 3) { dy = (tap * 11) >> 5; dx = tap - 3 * dy; } /* tap/3 for tap < 32 */         \
     const int tap_off = (dy * p.W + dx) * p.cin + ch_base + ch;                                      \
     const unsigned dst_ = smem_addr + (unsigned)(((DSTBUF) * STAGE + 8 * wave_u * LDS_ROW) * 4);     \
-    _Pragma("unroll") for (int i = 0; i < AP; ++i) if (i % 3 == (PART)) {                            \
+    _Pragma("unroll") for (int i = 0; i < AP; ++i) {                                                 \
       const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;                                                \
       const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;                  \
       const unsigned off = ok ? (unsigned)(a_pix[i] + tap_off) * 4u : OOB;                           \
-      if constexpr (DMA) {                                                                           \
-        UT_DIAG_A(dma16(a_words, dst_ + 32 * i * LDS_ROW * 4, off));                                 \
-      } else {                                                                                       \
-        UT_DIAG_A(a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off, 0, 0));              \
-      }                                                                                              \
+      dma16(a_words, dst_ + 32 * i * LDS_ROW * 4, off);                                              \
     }                                                                                                \
-    _Pragma("unroll") for (int i = 0; i < BP; ++i) if ((i + AP) % 3 == (PART)) {                     \
-      if constexpr (DMA) {                                                                           \
-        UT_DIAG_B(dma16(b_words, dst_ + (BM + 32 * i) * LDS_ROW * 4, b_off + i * b_row_step));       \
-      } else {                                                                                       \
-        UT_DIAG_B(b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off + i * b_row_step, 0, 0)); \
-      }                                                                                              \
-    }                                                                                                \
-    if ((PART) == 2) { /* advance to the next chunk */                                               \
-      b_off += BK * 4;                                                                               \
-      ch += BK;                                                                                      \
-      if (ch >= p.cslice) { ch -= p.cslice; ++tap; }                                                 \
-      if (tap >= taps) { tap -= taps; ch_base += p.cslice; }                                         \
-    }                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < BP; ++i)                                                   \
+      dma16(b_words, dst_ + (BM + 32 * i) * LDS_ROW * 4, b_off + i * b_row_step);                    \
+    UT_ADVANCE();                                                                                    \
   }
-#define UT_FETCH(DSTBUF) { UT_FETCH_PART(0, DSTBUF); UT_FETCH_PART(1, DSTBUF); UT_FETCH_PART(2, DSTBUF); }
+  /* (slice, tap, channel) of the next chunk */
+#define UT_ADVANCE()                                                                                 \
+  {                                                                                                  \
+    b_off += BK * 4;                                                                                 \
+    ch += BK;                                                                                        \
+    if (ch >= p.cslice) { ch -= p.cslice; ++tap; }                                                   \
+    if (tap >= taps) { tap -= taps; ch_base += p.cslice; }                                           \
+  }
 
-  // Finer interleave (UT_FINE_FETCH): one 1-KB piece in front of every MFMA quad instead of three bursts.
-  // The per-chunk tap arithmetic is done with piece 0 and kept in f_tap_off / f_dst.
+  // One LDS-DMA piece of the NEXT chunk per MFMA step, in two halves - the per-lane offset (vector ALU) and the
+  // transfer itself - so that each half can sit in its own MFMA gap.  The per-chunk tap arithmetic is done with
+  // piece 0 and kept in f_tap_off / f_dst.
   int f_tap_off = 0, f_dy = 0, f_dx = 0;
   unsigned f_dst = 0, f_off = 0;
-#define UT_FETCH_PIECE(IDX, DSTBUF)                                                                  \
-  {                                                                                                  \
-    if ((IDX) == 0) {                                                                                \
-      f_dy = 0; f_dx = 0;                                                                            \
-      if (p.ksize == 3) { f_dy = (tap * 11) >> 5; f_dx = tap - 3 * f_dy; }                           \
-      f_tap_off = (f_dy * p.W + f_dx) * p.cin + ch_base + ch;                                        \
-      f_dst = smem_addr + (unsigned)(((DSTBUF) * STAGE + 8 * wave_u * LDS_ROW) * 4);                 \
-    }                                                                                                \
-    if constexpr ((IDX) < AP) {                                                                      \
-      constexpr int i = (IDX);                                                                       \
-      const int iy = a_iy[i] + f_dy, ix = a_ix[i] + f_dx;                                            \
-      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;                  \
-      const unsigned off = ok ? (unsigned)(a_pix[i] + f_tap_off) * 4u : OOB;                         \
-      UT_DIAG_A(dma16(a_words, f_dst + 32 * i * LDS_ROW * 4, off));                                  \
-    } else if constexpr ((IDX) < AP + BP) {                                                          \
-      constexpr int i = (IDX) - AP;                                                                  \
-      UT_DIAG_B(dma16(b_words, f_dst + (BM + 32 * i) * LDS_ROW * 4, b_off + i * b_row_step));        \
-    }                                                                                                \
-    if ((IDX) == AP + BP - 1) { /* advance to the next chunk */                                      \
-      b_off += BK * 4;                                                                               \
-      ch += BK;                                                                                      \
-      if (ch >= p.cslice) { ch -= p.cslice; ++tap; }                                                 \
-      if (tap >= taps) { tap -= taps; ch_base += p.cslice; }                                         \
-    }                                                                                                \
-  }
-
   // the same piece in two halves: the per-lane offset (vector ALU) and the transfer itself, so that each half can
   // sit in its own MFMA gap
 #define UT_PIECE_ADDR(IDX, DSTBUF)                                                                   \
@@ -277,16 +219,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
 #define UT_PIECE_ISSUE(IDX)                                                                          \
   {                                                                                                  \
     if constexpr ((IDX) < AP) {                                                                      \
-      UT_DIAG_A(dma16(a_words, f_dst + 32 * (IDX) * LDS_ROW * 4, f_off));                            \
+      dma16(a_words, f_dst + 32 * (IDX) * LDS_ROW * 4, f_off);                            \
     } else if constexpr ((IDX) < AP + BP) {                                                          \
-      UT_DIAG_B(dma16(b_words, f_dst + (BM + 32 * ((IDX) - AP)) * LDS_ROW * 4, f_off));              \
+      dma16(b_words, f_dst + (BM + 32 * ((IDX) - AP)) * LDS_ROW * 4, f_off);              \
     }                                                                                                \
-    if ((IDX) == AP + BP - 1) { /* advance to the next chunk */                                      \
-      b_off += BK * 4;                                                                               \
-      ch += BK;                                                                                      \
-      if (ch >= p.cslice) { ch -= p.cslice; ++tap; }                                                 \
-      if (tap >= taps) { tap -= taps; ch_base += p.cslice; }                                         \
-    }                                                                                                \
+    if ((IDX) == AP + BP - 1) UT_ADVANCE();                                                          \
   }
 
   // MFMA C layout with the operands as above: lane = pixel (column fr of the 32-pixel fragment), register e =
@@ -341,29 +278,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
         acc[i][j][4 * g4 + 3] = bias_raw[j][g4].w + __uint_as_float(res_raw[i][j][g4].w);            \
       }
 
-#define UT_STAGE(buf)                                                                                \
-  if constexpr (DMA) {                                                                               \
-    dma_wait_all(); /* every piece of the next chunk has landed before the barrier publishes it */   \
-  } else {                                                                                           \
-    float* as_ = smem + (buf) * STAGE;                                                               \
-    float* bs_ = as_ + BM * LDS_ROW;                                                                 \
-    _Pragma("unroll") for (int i = 0; i < AP; ++i)                                                   \
-      *reinterpret_cast<u32x4*>(as_ + (r0 + 32 * i) * LDS_ROW + 4 * g) = a_reg[i];                   \
-    _Pragma("unroll") for (int i = 0; i < BP; ++i)                                                   \
-      *reinterpret_cast<u32x4*>(bs_ + (r0 + 32 * i) * LDS_ROW + 4 * g) = b_reg[i];                   \
-  }
-
-#ifdef UT_DIAG_NO_STAGE
-#define UT_MAYBE_STAGE(b) asm volatile("" ::"v"(a_reg[0]), "v"(b_reg[0]))
-#else
-#define UT_MAYBE_STAGE(b) UT_STAGE(b)
-#endif
+  /* every piece of the next chunk has landed before the barrier publishes it */
+#define UT_STAGE() dma_wait_all()
 
   // Fragment reads (one b128 per 32-row fragment per 8 k) into register set X or Y, and the 4*MI*NI MFMAs
   // that consume a set.
 #define UT_READ(SET, buf, q)                                                                         \
   {                                                                                                  \
-    const int koff_ = DMA ? 4 * ((2 * (q) + fh) ^ ((fr >> 1) & 7)) : 4 * fh + 8 * (q);               \
+    const int koff_ = 4 * ((2 * (q) + fh) ^ ((fr >> 1) & 7));                                        \
     const float* as = smem + (buf) * STAGE + (wm * (MI * 32) + fr) * LDS_ROW + koff_;                \
     const float* bs = smem + (buf) * STAGE + BM * LDS_ROW + (wn * (NI * 32) + fr) * LDS_ROW + koff_; \
     _Pragma("unroll") for (int i = 0; i < MI; ++i) af##SET[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDS_ROW); \
@@ -428,8 +350,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
   // Fine interleave: one LDS-DMA piece in front of every MFMA step (a step = one k of all MI*NI accumulators),
   // instead of three bursts per chunk: a piece issued among bare MFMAs costs the issuing wave ~60 cycles, one
   // issued next to other pieces and the fragment reads 100-185 (MI355X_MICROARCH.md, LDS-DMA piece issue cost).
-#ifndef UT_WHOLE_STEP     /* the piece's offset arithmetic and its transfer sit in different MFMA gaps (+1.1..1.5 %):
-                             in-order issue stalls the wave's next MFMA only by what exceeds one 64-cycle gap */
+  // The piece's offset arithmetic and its transfer sit in different MFMA gaps (+1.1..1.5 %): in-order issue stalls the
+  // wave's next MFMA only by what exceeds one 64-cycle gap.
 #define UT_STEP_FINE(SET, C, IDX, DSTBUF)                                                            \
   {                                                                                                  \
     UT_PIECE_ADDR(IDX, DSTBUF); UT_PIN();                                                            \
@@ -440,10 +362,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
         if (i + j > 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf##SET[j].C, af##SET[i].C, acc[i][j], 0, 0, 0); \
     UT_PIN();                                                                                        \
   }
-#else
-#define UT_STEP_FINE(SET, C, IDX, DSTBUF)                                                            \
-  { UT_FETCH_PIECE(IDX, DSTBUF); UT_PIN(); UT_MFMA_STEP(SET, C) UT_PIN(); }
-#endif
 #define UT_GROUP_FINE(SET, G, DSTBUF)                                                                \
   {                                                                                                  \
     UT_STEP_FINE(SET, x, 4 * (G) + 0, DSTBUF) UT_STEP_FINE(SET, y, 4 * (G) + 1, DSTBUF)              \
@@ -452,11 +370,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
 #define UT_GROUP_FINE_R(SET, G, DSTBUF, READ) { READ; UT_PIN(); UT_GROUP_FINE(SET, G, DSTBUF); }
 #define UT_CHUNK_FINE(buf)                                                                           \
   {                                                                                                  \
-    static_assert(12 >= AP + BP, "pieces must fit the MFMA steps in front of the barrier");          \
     UT_GROUP_FINE_R(X, 0, (buf) ^ 1, UT_READ(Y, buf, 1));                                            \
     UT_GROUP_FINE_R(Y, 1, (buf) ^ 1, UT_READ(X, buf, 2));                                            \
     UT_GROUP_FINE_R(X, 2, (buf) ^ 1, UT_READ(Y, buf, 3));                                            \
-    UT_MAYBE_STAGE((buf) ^ 1);                                                                       \
+    UT_STAGE();                                                                       \
     UT_BARRIER();                                                                                    \
     UT_READ(X, (buf) ^ 1, 0); UT_PIN(); UT_MFMA(Y); UT_PIN();                                        \
   }
@@ -465,51 +382,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
 #define UT_STEP_INIT(SET, C, Q, TILE) { UT_INIT_LOAD_PART(TILE, Q); UT_PIN(); UT_MFMA_STEP(SET, C) UT_PIN(); }
 #define UT_CHUNK_FINE_LAST(buf, TILE)                                                                \
   {                                                                                                  \
-    static_assert(8 >= AP + BP, "the third group carries the accumulator requests");                 \
     UT_READ(Y, buf, 1); UT_PIN(); UT_GROUP_FINE(X, 0, (buf) ^ 1);                                    \
     UT_READ(X, buf, 2); UT_PIN(); UT_GROUP_FINE(Y, 1, (buf) ^ 1);                                    \
     UT_READ(Y, buf, 3); UT_PIN();                                                                    \
     UT_STEP_INIT(X, x, 0, TILE) UT_STEP_INIT(X, y, 1, TILE) UT_STEP_INIT(X, z, 2, TILE) UT_STEP_INIT(X, w, 3, TILE) \
-    UT_MAYBE_STAGE((buf) ^ 1);                                                                       \
+    UT_STAGE();                                                                       \
     UT_BARRIER();                                                                                    \
-    UT_READ(X, (buf) ^ 1, 0); UT_PIN(); UT_TAIL_MFMA(Y); UT_PIN();                                   \
+    UT_READ(X, (buf) ^ 1, 0); UT_PIN(); UT_TAIL_EPI(Y); UT_PIN();                                   \
   }
-#ifdef UT_PLAIN_TAIL      /* diag: round-robin last group, epilogue behind it */
-#define UT_TAIL_MFMA(SET) UT_MFMA(SET)
-#else
-#define UT_TAIL_MFMA(SET) { UT_TAIL_EPI(SET); epi_done = true; }
-#endif
-  // One chunk, software pipelined against LDS latency and the barrier.  On entry set X holds the q=0
-  // fragments of this chunk (read under the previous chunk's last MFMA group).  The reads of group q+1 are
-  // issued before the MFMAs of group q; the next chunk is staged and the barrier passed BEFORE the last
-  // MFMA group, under which the q=0 fragments of the next chunk are read from the other buffer.
-#define UT_CHUNK(buf, F0, F1, F2)                                                                    \
-  {                                                                                                  \
-    F0; UT_READ(Y, buf, 1); UT_PIN(); UT_MFMA(X); UT_PIN();                                          \
-    F1; UT_READ(X, buf, 2); UT_PIN(); UT_MFMA(Y); UT_PIN();                                          \
-    F2; UT_READ(Y, buf, 3); UT_PIN(); UT_MFMA(X); UT_PIN();                                          \
-    UT_MAYBE_STAGE((buf) ^ 1);                                                                       \
-    UT_BARRIER();                                                                                    \
-    UT_READ(X, (buf) ^ 1, 0); UT_PIN(); UT_MFMA(Y); UT_PIN();                                        \
-  }
-#ifdef UT_DIAG_NO_BARRIER
-#define UT_BARRIER()
-#else
 #define UT_BARRIER() __syncthreads()
-#endif
 
-#ifdef UT_STAMPS
-#define UT_STAMP(IDX)                                                                                \
-  if (tid == 0 && blockIdx.x < 4096) {                                                               \
-    __builtin_amdgcn_sched_barrier(0);                                                               \
-    p.stamps[blockIdx.x * 8 + (IDX)] = (long long)__builtin_amdgcn_s_memtime();                      \
-    __builtin_amdgcn_sched_barrier(0);                                                               \
-  }
-  int tiles_done = 0;
-#else
-#define UT_STAMP(IDX)
-#endif
-  UT_STAMP(0);
   // Stagger the workgroups that share a CU.  Co-resident workgroups run the same program on the same
   // pipes; sharing the matrix pipe preserves their phase difference, and they are dispatched together, so
   // without this they stay in lockstep for the whole (persistent) kernel: every non-MFMA stretch of a chunk
@@ -517,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
   // per co-resident rank keeps one workgroup in its MFMA stretch while the other is between chunks.
   {
     const int rank = __builtin_amdgcn_readfirstlane((int)blockIdx.x / p.num_cu);   // 0 .. resident-1
-    const int steps = rank * p.stagger;       // units of 512 cycles
+    const int steps = rank * stagger;         // units of 512 cycles
     for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(8);
   }
   // Tile-queue slot: one int behind the staging area, accessed with explicit DS instructions - a `volatile int*`
@@ -528,9 +410,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
   UT_SETUP(tile);
   UT_FETCH(0);
   UT_INIT_LOAD(tile);
-  UT_STAGE(0);
+  UT_STAGE();
   __syncthreads();
-  UT_STAMP(1);
 
   int buf = 0;
   f32x16 acc[MI][NI];
@@ -544,36 +425,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
 
     // steady state: fetch chunk c+1 (loads stay in flight under the MFMAs), compute chunk c
     for (int c = 0; c + 1 < n_chunks; ++c) {
-#ifndef UT_DIAG_NO_FETCH    /* timing-only ablations for tools/diag (results are wrong with any of them) */
-#ifdef UT_BURST_FETCH
-      UT_FETCH(buf ^ 1);
-      UT_CHUNK(buf, , , );
-#else
-      if constexpr (DMA && FINE) {
-        UT_CHUNK_FINE(buf);
-      } else {
-        UT_CHUNK(buf, UT_FETCH_PART(0, buf ^ 1), UT_FETCH_PART(1, buf ^ 1), UT_FETCH_PART(2, buf ^ 1));
-      }
-#endif
-#else
-      UT_CHUNK(buf, , , );
-#endif
+      UT_CHUNK_FINE(buf);
       buf ^= 1;
       if (c == 0 && tid == 0) UT_SLOT_WRITE(grid + ticket);   // ordered before its read by the later chunk barriers
     }
-#ifdef UT_STAMPS
-    if (tiles_done == 0) UT_STAMP(2);
-#endif
     // The next tile comes from a device-wide queue (first round: static XCD-contiguous slots; afterwards one
     // atomic per workgroup per tile, taken a whole tile ahead by wave 0 and handed over through LDS - the chunk
     // barriers in between order it).  Dynamic hand-out keeps every CU busy when the tile count is not a multiple
     // of the resident workgroups; a static stride left up to half of them idle in the last round.
-    // last chunk: fetch the first chunk, bias and residual of the NEXT tile under it (without a next tile the
-    // staging inside UT_CHUNK rewrites stale registers into the idle buffer: harmless)
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int e_tm = tm, e_tn = tn;
     const float e_floor = p.relu ? 0.f : -__builtin_huge_valf();   // 0 with ReLU, -inf without: one v_max, no branch
-    bool epi_done = false;
     if (n_chunks <= 2) {                  // too few chunk barriers to order the queue slot: do it explicitly
       if (n_chunks == 1 && tid == 0) UT_SLOT_WRITE(grid + ticket);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -582,58 +444,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     int next_v;
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(next_v) : "v"(slot_addr) : "memory");
     const int next = __builtin_amdgcn_readfirstlane(next_v);
-    const bool has_next = next < n_tiles;
-#ifndef UT_LAST_BURST
-    if constexpr (DMA && FINE && AP + BP <= 8) {
-      // no branch: without a next tile (next >= n_tiles) every row is beyond M and the requests return zeros
-      UT_SETUP(next);
-      UT_CHUNK_FINE_LAST(buf, next);
-    } else
-#endif
-    {
-      if (has_next) {
-        UT_SETUP(next);
-        UT_FETCH(buf ^ 1);
-        UT_INIT_LOAD(next);
-      }
-      UT_CHUNK(buf, , , );
-    }
+    // Last chunk: the first chunk, bias and residual of the NEXT tile are fetched under it, and the finished
+    // accumulators are stored ((ReLU) + 16-byte stores through a buffer descriptor: pixels beyond M and channel quads
+    // beyond cout get an out-of-range offset and are dropped) in the MFMA gaps of its last group.  No branch: without
+    // a next tile (next >= n_tiles) every row is beyond M and the requests return zeros.
+    UT_SETUP(next);
+    UT_CHUNK_FINE_LAST(buf, next);
     buf ^= 1;
-#ifdef UT_STAMPS
-    if (tiles_done == 0) UT_STAMP(3);
-#endif
-
-    // epilogue of the finished tile: (ReLU) + store through a buffer descriptor (pixels beyond M and channel
-    // quads beyond cout get an out-of-range offset and are dropped): straight-line 16-byte stores, so the
-    // compiler counts them exactly instead of draining the memory pipe before the next tile.
-    if (!epi_done) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          UT_EPI_PART(i, j, 0); UT_EPI_PART(i, j, 1); UT_EPI_PART(i, j, 2); UT_EPI_PART(i, j, 3);
-        }
-    }
-#ifdef UT_STAMPS
-    if (tiles_done == 0) UT_STAMP(4);
-    if (tiles_done == 1) UT_STAMP(5);
-    ++tiles_done;
-#endif
-    if (!has_next) break;
+    if (next >= n_tiles) break;
     tile = next;
   }
-#ifdef UT_STAMPS
-  UT_STAMP(6);
-  if (tid == 0 && blockIdx.x < 4096) p.stamps[blockIdx.x * 8 + 7] = tiles_done;
-#endif
 #undef UT_SLOT_WRITE
 #undef UT_SETUP
 #undef UT_FETCH
-#undef UT_FETCH_PART
+#undef UT_ADVANCE
 #undef UT_INIT_LOAD
 #undef UT_INIT_COMBINE
 #undef UT_STAGE
-#undef UT_CHUNK
 #undef UT_READ
 #undef UT_MFMA
 #undef UT_MFMA_STEP
@@ -643,7 +470,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
 #undef UT_Q_STORE
 #undef UT_TAIL_Q
 #undef UT_TAIL_EPI
-#undef UT_TAIL_MFMA
 #undef UT_STEP_FINE
 #undef UT_GROUP_FINE_R
 #undef UT_STEP_INIT
@@ -651,25 +477,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
 #undef UT_INIT_LOAD_PART
 #undef UT_GROUP_FINE
 #undef UT_CHUNK_FINE
-#undef UT_FETCH_PIECE
 #undef UT_PIECE_ADDR
 #undef UT_PIECE_ISSUE
 #undef UT_BARRIER
-#undef UT_MAYBE_STAGE
 }
 
-template <int BM, int BN, int WR, int WC, bool DMA, bool NCHW = false, bool C32 = false>
+template <int BM, int BN, int WR, int WC, bool NCHW = false, bool C32 = false>
 static hipError_t launch_cfg(const ConvLaunch& c, hipStream_t s) {
   const int M = c.n_img * c.Ho * c.Wo;
   const int tiles_m = (M + BM - 1) / BM;
   const int tiles_n = (c.cout_store + BN - 1) / BN;
   const int n_tiles = tiles_m * tiles_n;
-  const size_t lds = 2 * (size_t)(BM + BN) * lds_row<DMA>() * sizeof(float) + 16;   // + tile-queue slot
+  const size_t lds = 2 * (size_t)(BM + BN) * LDS_ROW * sizeof(float) + 16;   // + tile-queue slot
   // the attribute belongs to (kernel, device): one bit per device, set on the first launch there
   static std::atomic<unsigned long long> attr_set{0};
   const unsigned long long dev_bit = (c.device >= 0 && c.device < 64) ? 1ull << c.device : 0ull;
   if (!(attr_set.load(std::memory_order_relaxed) & dev_bit) || !dev_bit) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, DMA, NCHW, C32>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, NCHW, C32>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set.fetch_or(dev_bit, std::memory_order_relaxed);
@@ -677,14 +501,12 @@ static hipError_t launch_cfg(const ConvLaunch& c, hipStream_t s) {
   // persistent grid: as many workgroups as stay resident (LDS bound), never more than tiles
   const int per_cu = (int)((160 * 1024) / lds);
   int grid = c.num_cu * (per_cu < 1 ? 1 : per_cu);
-  if (c.persist_limit > 0 && grid > c.persist_limit) grid = c.persist_limit;
-  if (c.persist_limit < 0) grid = n_tiles;     // one tile per workgroup (hardware dispatch order)
   if (grid > n_tiles) grid = n_tiles;
-  // automatic stagger: with r co-resident workgroups a chunk takes r x (its MFMA time) of wall time, so the
+  // start stagger of co-resident workgroups: with r of them a chunk takes r x (its MFMA time) of wall time, so the
   // even spacing between ranks is one chunk's MFMA time = (MI*NI) x 16 MFMAs x 64 cycles = (MI*NI) x 2 units
-  ConvLaunch cl = c;
-  if (c.stagger < 0) cl.stagger = grid > c.num_cu ? (BM / WR / 32) * (BN / WC / 32) * 2 : 0;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, DMA, NCHW, C32>), dim3(grid), dim3(256), lds, s, cl, tiles_n, n_tiles);
+  const int stagger = grid > c.num_cu ? (BM / WR / 32) * (BN / WC / 32) * 2 : 0;
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, NCHW, C32>), dim3(grid), dim3(256), lds, s, c, tiles_n, n_tiles,
+                     stagger);
   return hipGetLastError();
 }
 
@@ -697,25 +519,21 @@ hipError_t launch_conv_igemm(const ConvLaunch& c, hipStream_t s) {
   // 32-bit byte offsets into the activation / residual tensors
   if ((size_t)c.n_img * c.H * c.W * c.cin * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
   if ((size_t)c.n_img * c.Ho * c.Wo * c.cout_store * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
-  static const int use_patch = [] { const char* e = getenv("UT_CONV_PATCH"); return e ? atoi(e) : 1; }();
-  if (use_patch && conv_patch_applicable(c)) return launch_conv_patch(c, s);
-  static const int dma = [] { const char* e = getenv("UT_CONV_DMA"); return e ? atoi(e) : 7; }();   // bit per tile config
-  if (c.out_nchw) return launch_cfg<64, 128, 1, 4, true, true>(c, s);      // projection: the only NCHW output
-  if (c.cout_store <= 32) return (dma & 1) ? launch_cfg<128, 32, 4, 1, true>(c, s) : launch_cfg<128, 32, 4, 1, false>(c, s);
-  static const int c32 = [] { const char* e = getenv("UT_CONV_C32"); return e ? atoi(e) : 1; }();
-  const bool u = c32 && c.cslice == BK;     // backbone convolutions: scalar tap bookkeeping
-  if (c.cout_store <= 64 && (dma & 2) && u) return launch_cfg<128, 64, 2, 2, true, false, true>(c, s);
-  if (c.cout_store <= 64) return (dma & 2) ? launch_cfg<128, 64, 2, 2, true>(c, s) : launch_cfg<128, 64, 2, 2, false>(c, s);
-  // few-tile launches (the head: 73,728 pixels = 576 tiles of 128 rows on 512 resident slots, i.e. two rounds the
-  // second of which is 12 % full): half-height tiles, three workgroups per CU
-  static const int small_m = [] { const char* e = getenv("UT_CONV_SMALL_M"); return e ? atoi(e) : 5; }();
-  {
-    const long M = (long)c.n_img * c.Ho * c.Wo;
-    const long tiles128 = ((M + 127) / 128) * ((c.cout_store + 127) / 128);
-    if (small_m > 0 && tiles128 <= (long)small_m * c.num_cu) return launch_cfg<64, 128, 1, 4, true>(c, s);
-  }
-  if ((dma & 4) && u) return launch_cfg<128, 128, 2, 2, true, false, true>(c, s);
-  return (dma & 4) ? launch_cfg<128, 128, 2, 2, true>(c, s) : launch_cfg<128, 128, 2, 2, false>(c, s);
+  // One dispatch, by shape:
+  //  layer1 (3x3 stride 1, 32 -> 32 channels)                      halo-patch kernel (conv_patch.hip)
+  //  projection (the only NCHW output)                             64x128 tile
+  //  backbone, cout <= 64  (channel slice == chunk width)          128x64 tile, three workgroups per CU
+  //  few tiles (the head: 73,728 pixels = 576 tiles of 128 rows on 512 resident slots, i.e. two rounds the
+  //  second of which is 12 % full)                                 64x128 tile, three workgroups per CU
+  //  backbone, cout > 64 / everything else                         128x128 tile
+  if (conv_patch_applicable(c)) return launch_conv_patch(c, s);
+  if (c.out_nchw) return launch_cfg<64, 128, 1, 4, true>(c, s);
+  const bool c32 = c.cslice == BK;          // scalar tap bookkeeping
+  if (c.cout_store <= 64 && c32) return launch_cfg<128, 64, 2, 2, false, true>(c, s);
+  const long M = (long)c.n_img * c.Ho * c.Wo;
+  const long tiles128 = ((M + 127) / 128) * ((c.cout_store + 127) / 128);
+  if (tiles128 <= 5l * c.num_cu) return launch_cfg<64, 128, 1, 4>(c, s);
+  return c32 ? launch_cfg<128, 128, 2, 2, false, true>(c, s) : launch_cfg<128, 128, 2, 2>(c, s);
 }
 
 }  // namespace ut

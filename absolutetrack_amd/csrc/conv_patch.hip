@@ -198,17 +198,6 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
   int next = slot_read(2);
   int cur = 0;
 
-#ifdef UT_STAMPS
-  int tiles_done = 0;
-#define UTP_STAMP(IDX)                                                                               \
-  if (tid == 0 && blockIdx.x < 4096 && tiles_done == 1) {                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                               \
-    p.stamps[blockIdx.x * 8 + (IDX)] = (long long)__builtin_amdgcn_s_memtime();                      \
-    __builtin_amdgcn_sched_barrier(0);                                                               \
-  }
-#else
-#define UTP_STAMP(IDX)
-#endif
 #define UTP_EPILOGUE(M_)                                                                              \
   {                                                                                                  \
     const int m_ = (M_);                                                                             \
@@ -231,7 +220,6 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
   f32x16 ready = init_combine();      // bias + residual of the tile about to be computed
   f32x16 acc;
   for (;;) {
-    UTP_STAMP(0);
     const bool has_next = next < n_tiles;
     if (late && have_prev) { UTP_EPILOGUE(prev_m); }
     acc = ready;
@@ -239,7 +227,6 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
     const int ticket = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, q_rsrc, q_off, 0, 0);
     int n_row0 = 0, n_y0 = 0, n_x0 = 0;
     if (has_next) tile_origin(next, n_row0, n_y0, n_x0);
-    UTP_STAMP(1);
 
     const float* patch = patch0 + cur * P_FLOATS;
     // 9 taps x 4 k-groups, fragments double buffered in registers.  The requests for the NEXT tile (patch
@@ -274,7 +261,6 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
         // everything requested for the next tile was issued at least two taps ago: drain the counter, publish
         // the ticket and combine bias+residual NOW, in front of the last MFMA group and of the stores (vmcnt
         // counts stores too: waiting at the barrier would cost every wave a write round trip per tile)
-        UTP_STAMP(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) slot_write(cur, grid + ticket);
         if (has_next) ready = init_combine();
@@ -285,23 +271,17 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
 #undef UTP_READ
 #undef UTP_MFMA
 #undef UTP_PIN
-    UTP_STAMP(3);
     // epilogue: (ReLU) + 4 x 16-byte stores per lane.  Waves 0-3 store right after their MFMAs; waves 4-7 (the
     // SIMD partners of 0-3: a workgroup's waves w and w+4 share a SIMD) keep the tile in registers and store it at
     // the top of the NEXT tile instead, so that within a barrier interval one partner stores while the other
     // still feeds the matrix pipe - partners running the same program otherwise reach their store phase together.
     if (!late) { UTP_EPILOGUE((c_row0 + c_y0 + ly) * W + c_x0 + lx); }
     else { prev_m = (c_row0 + c_y0 + ly) * W + c_x0 + lx; have_prev = true; }
-    UTP_STAMP(4);
     if (!has_next) break;
     // every wave's pieces of the next patch have landed and everyone is done reading the current one
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
     __builtin_amdgcn_s_barrier();
-    UTP_STAMP(5);
     const int next2 = slot_read(cur);
-#ifdef UT_STAMPS
-    ++tiles_done;
-#endif
     tile = next;
     next = next2;
     c_row0 = n_row0; c_y0 = n_y0; c_x0 = n_x0;

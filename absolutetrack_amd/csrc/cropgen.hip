@@ -111,8 +111,11 @@ __device__ inline void fit_crop_camera(const double* c2w0, const float* pts, int
   inv4(o.w2e, o.c2w);              // crop.py:81
 }
 
-// middle of the bounding box in fp32 like (pts.min + pts.max) / 2.0 on float32 points (crop.py:60)
-__device__ inline void bbox_center(const float* pts, int n_pts, double* center) {
+// middle of the bounding box, (pts.min + pts.max) / 2.0 (crop.py:60): in fp32 like numpy on float32 points
+// (the tracker path, whose cameras are float64 so that the rest of its chain is float64 in the reference too),
+// or exactly (the torch_data path, which is compared with the reference's functions run on float64 copies of
+// its all-float32 inputs because their float32 LAPACK chain is not a machine-independent bit pattern)
+__device__ inline void bbox_center(const float* pts, int n_pts, double* center, bool exact = false) {
   float lo[3], hi[3];
   for (int d = 0; d < 3; ++d) { lo[d] = 3.0e38f; hi[d] = -3.0e38f; }
   for (int q = 0; q < n_pts; ++q)
@@ -120,7 +123,8 @@ __device__ inline void bbox_center(const float* pts, int n_pts, double* center) 
       lo[d] = fminf(lo[d], pts[3 * q + d]);
       hi[d] = fmaxf(hi[d], pts[3 * q + d]);
     }
-  for (int d = 0; d < 3; ++d) center[d] = (double)((lo[d] + hi[d]) / 2.0f);
+  for (int d = 0; d < 3; ++d)
+    center[d] = exact ? ((double)lo[d] + (double)hi[d]) / 2.0 : (double)((lo[d] + hi[d]) / 2.0f);
 }
 
 }  // namespace
@@ -203,14 +207,15 @@ __global__ __launch_bounds__(64) void cropgen_kernel(CropGenArgs g) {
 // extrinsics/intrinsics and the pixel homography of data_transform.py:57-76
 //   resample_xf = K_orig44 @ world_to_eye_orig @ eye_to_world_new @ K_new44^-1      (crop pixel -> source pixel).
 // The reference runs this chain in float32 (numpy keeps the dtype of the float32 sample through every
-// np.linalg.inv); here it is float64 and rounded once at the end.
+// np.linalg.inv, i.e. OpenBLAS sgesv); here it is float64 and rounded once at the end, which reproduces the
+// reference's own functions fed float64 copies of the same values (tests/golden/torch_data.npz, *_f64chain).
 __global__ __launch_bounds__(64) void cropmat_kernel(CropMatArgs g) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= g.n_frames * g.n_views) return;
   const int frame = i / g.n_views;
   const float* pts = g.crop_points + (size_t)frame * g.n_pts * 3;
   double center[3];
-  bbox_center(pts, g.n_pts, center);
+  bbox_center(pts, g.n_pts, center, true);
   double w2e_orig[16], c2w0[16];
   for (int k = 0; k < 16; ++k) w2e_orig[k] = (double)g.orig_extrinsics[(size_t)i * 16 + k];
   inv4(w2e_orig, c2w0);            // camera_to_world_xf=np.linalg.inv(world_to_eye_xf)  (data_transform.py:192)

@@ -48,8 +48,6 @@ constexpr int kMaxChunk = 7281;   // 48*48*32*4 B per crop under 2^31 - 256 byte
 struct ut_context {
   int device = 0;
   int num_cu = 256;
-  int persist_limit = 0;
-  int stagger = -1;
   std::string err;
   std::vector<void*> allocs;        // everything to hipFree at destroy
   // weights
@@ -385,7 +383,7 @@ int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, fl
   c.k_total = cw.k_total; c.k_pad = cw.k_pad; c.cslice = cw.cslice;
   c.ksize = cw.ksize; c.stride = cw.stride; c.pad = cw.pad;
   c.relu = relu; c.out_nchw = nchw;
-  c.device = h->device; c.num_cu = h->num_cu; c.persist_limit = h->persist_limit; c.stagger = h->stagger;
+  c.device = h->device; c.num_cu = h->num_cu;
   if (h->counter_next >= kMaxCounters) {   // recycle: stream order puts the memset behind the earlier launches
     int rc0 = begin_call(h, s);
     if (rc0) return rc0;
@@ -438,8 +436,6 @@ int ut_create(int device, const float* blob, size_t n_floats, ut_handle* out) {
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->num_cu = cus;
-    if (const char* e = getenv("UT_PERSIST_LIMIT")) h->persist_limit = atoi(e);
-    if (const char* e = getenv("UT_STAGGER")) h->stagger = atoi(e);
   }
   Cursor c{blob, n_floats};
   int rc = UT_OK;

@@ -29,12 +29,7 @@ struct ConvLaunch {
   int out_nchw;
   int device;          // HIP device the launch goes to (the dynamic-LDS attribute is set once per device)
   int num_cu;          // compute units of the device (persistent grid sizing)
-  int persist_limit;   // > 0: cap on the persistent grid (debug / tuning)
   unsigned* tile_counter;   // device word, zero before the launch: dynamic tile queue of the persistent grid
-  int stagger;         // start delay per co-resident workgroup rank, units of 512 cycles; < 0 = automatic
-#ifdef UT_STAMPS
-  long long* stamps;   // diagnostic builds only (tools/diag): [workgroup][8] s_memtime stamps
-#endif
 };
 
 hipError_t launch_conv_igemm(const ConvLaunch& c, hipStream_t s);

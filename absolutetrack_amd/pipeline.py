@@ -237,11 +237,16 @@ def make_batch(plan: dict, src_u8: torch.Tensor, device, independent_frames: boo
 
 # ----------------------------------------------------------------------------- the hot path
 class HotPath:
-    """warp -> backbone -> fuse/temporal/regress -> FK over one FrameBatch; all buffers preallocated."""
+    """warp -> backbone -> fuse/temporal/regress -> FK over one FrameBatch; all buffers preallocated.
+
+    The engine's index checks run deferred (no stream synchronisation inside `step`, so the host keeps launching
+    ahead of the GPU): a bad index tensor makes the device skip that call's work, and `check()` - call it wherever the
+    records are consumed - raises IndexError for it."""
 
     def __init__(self, engine: _native.HipEngine, hand_model_mm: HandModel, known_skeleton: bool = True,
                  remap_mode: int = _native.UT_REMAP_CV2_FIXED):
         self.engine = engine
+        engine.set_index_checks(deferred=True)
         self.mode = _native.UT_MODE_KNOWN if known_skeleton else _native.UT_MODE_UNKNOWN
         self.remap_mode = remap_mode
         dev = engine.device
@@ -280,6 +285,10 @@ class HotPath:
         rec[:, : arch.POSE_REC].copy_(pose)
         rec[:, arch.POSE_REC:].copy_(kp.reshape(s, -1))
         return rec
+
+    def check(self):
+        """Synchronises; raises IndexError if an index check failed in any step since the last call."""
+        self.engine.poll_status()
 
     def _pose_buf(self, s):
         if getattr(self, "_pose", None) is None or self._pose.shape[0] != s:

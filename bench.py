@@ -13,7 +13,9 @@ all-gathered over RCCL at the end of every step.
 
 Extra JSON objects: `roofline` (the implicit-GEMM convolution kernel, hipEvent-timed per launch in a
 separate profiling pass on the launch stream) and `cpu_baseline` (the CPU oracle's restatement of the
-same path on a bounded sample, rank 0, N=1 only).
+same path on a bounded sample, rank 0, N=1 only).  The same checker leg also drives all 369 label frames of
+recording_00 as one sequence (temporal memory engaged) through the drop-in HandTracker and the oracle and
+reports `mpjpe_delta_mm` (BASELINE.json: within 0.05 mm); --parity-frames 0 skips it.
 """
 import argparse
 import json
@@ -40,6 +42,8 @@ def main():
     ap.add_argument("--mode", choices=["known", "unknown"], default="known")
     ap.add_argument("--chunk", type=int, default=0, help="crops per backbone pass (0 = library default)")
     ap.add_argument("--cpu-frames", type=int, default=768, help="label frames timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--parity-frames", type=int, default=369,
+                    help="label frames of recording_00 run as a sequence against the oracle for mpjpe_delta_mm (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cropgen-in-step", action="store_true",
                     help="also regenerate the crop cameras from the label poses inside every step (SURVEY 8 f1)")
@@ -116,6 +120,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    hot.check()            # deferred index checks of every step above
     assert out.shape == (s_local * world, pipeline.RECORD)
     finite = bool(torch.isfinite(out).all().item())
     if planner is not None and not bool(planner.ok.item()):
@@ -134,15 +139,21 @@ def main():
             hot.step(batch)
         ms, launches, flops = eng.profile_end()
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command (FETCH_SIZE and
-        # WRITE_SIZE cannot share a pass), summarised by tools/pmc_traffic.py into profiles/
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
-        if os.path.exists(tpath) and f_local == 1024 and known:
-            traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
+        # HBM bytes per launch cannot be measured by this process: they come from separate rocprofv3 --pmc passes of
+        # this same command (FETCH_SIZE and WRITE_SIZE cannot share a pass), summarised by tools/pmc_traffic.py into
+        # profiles/ and quoted here with their source; null when no summary matches this workload
+        traffic, traffic_source = None, None
+        prof_dir = os.path.join(ROOT, "profiles")
+        cands = sorted(f for f in (os.listdir(prof_dir) if os.path.isdir(prof_dir) else []) if f.endswith("_conv_traffic.json"))
+        if cands and f_local == 1024 and known:
+            tj = json.load(open(os.path.join(prof_dir, cands[-1])))
+            traffic = tj.get("traffic_bytes_per_launch")
+            traffic_source = (f"profiles/{cands[-1]}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `{tj.get('label', '')}` "
+                              "(an earlier run of this command, not this process); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024")
         roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (all instantiations) + conv3x3_c32_patch_kernel (layer1)",
                     "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": traffic_source,
                     "launches_per_step": launches // n_prof, "avg_launch_ms": round(ms / max(launches, 1), 5),
                     "flops_per_launch_avg": flops / max(launches, 1),
                     "whole_step_tflops": round(value * flops_hf / 1e12, 3)}
@@ -158,6 +169,16 @@ def main():
                "sample": f"{args.cpu_frames} label frames ({r['hand_frames']} hand-frames) of the same workload, "
                          f"oracle resample+network+FK, {r['seconds']:.1f} s"}
 
+    parity = None
+    if rank == 0 and world == 1 and args.parity_frames > 0:
+        from oracle import checks      # checker leg, like cpu_baseline above: never inside the timed region
+        eng.close()
+        r = checks.run_recording00(sd, str(device), known=known, n_frames=args.parity_frames)
+        parity = {k: r[k] for k in ("mode", "frames", "hand_frames", "mpjpe_build_mm", "mpjpe_oracle_mm", "mpjpe_delta_mm",
+                                    "max_joint_angle_err_rad", "max_keypoint_err_mm", "oracle_cpu_seconds") if k in r}
+        if not known:
+            parity.update({k: r[k] for k in ("scale_mean_build", "scale_mean_oracle", "scale_mean_abs_diff")})
+
     if rank == 0:
         line = {
             "metric": "hand-frames/sec", "value": round(value, 1), "unit": "hand-frames/s", "n_gpus": world,
@@ -171,6 +192,7 @@ def main():
                        "crops_per_step": n_local * world, "src_image": "480x636 u8 x 4 cameras",
                        "parallelism": f"frame-shard x{world}", "outputs_finite": finite},
             "roofline": roofline, "cpu_baseline": cpu,
+            "mpjpe_delta_mm": None if parity is None else parity["mpjpe_delta_mm"], "parity_recording_00": parity,
         }
         print(json.dumps(line), flush=True)
     eng.close()

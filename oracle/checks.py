@@ -70,6 +70,7 @@ def run_small_end_to_end(sd_np, n_frames: int = 2, device: str = "cuda:0", known
         batch = pipeline.make_batch(plan, torch.from_numpy(frames.reshape(-1, 480, 636)), device)
         hot = pipeline.HotPath(eng, hm, known_skeleton=known)
         rec = hot.step(batch).cpu().numpy()
+        hot.check()
         gpu_crops = hot._bufs[1].cpu().numpy()
     finally:
         eng.close()

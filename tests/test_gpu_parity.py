@@ -424,29 +424,34 @@ def test_two_handles_on_one_device_are_independent(engine):
     assert torch.equal(engine.backbone(crops), a)           # the first handle outlives the second
 
 
-def test_alternative_kernel_paths_agree():
-    """The env-selected alternatives of the convolution dispatch (register-staged operands instead of LDS-DMA, the
-    generic kernel instead of the halo-patch kernel, vector instead of scalar tap bookkeeping, full-height tiles for
-    the head, one tile per workgroup instead of the persistent queue) compute the same features.  The switches are
-    read once per process, hence subprocesses."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys, torch; sys.path.insert(0, %r);"
-            "from absolutetrack_amd import _native, synth;"
-            "eng = _native.HipEngine(synth.synthetic_state_dict(0), 'cuda:0');"
-            "x = torch.from_numpy(synth.synthetic_crops(5, seed=3)).to('cuda:0');"
-            "f = eng.backbone(x).double().cpu();"
-            "print('FEAT', ' '.join(repr(float(v)) for v in [f.sum(), f.abs().sum(), (f * f).sum(), f[3].sum()]))") % root
-    outs = {}
-    for name, env in (("default", {}), ("no_dma", {"UT_CONV_DMA": "0"}), ("no_patch", {"UT_CONV_PATCH": "0"}),
-                      ("no_c32", {"UT_CONV_C32": "0"}), ("no_small_m", {"UT_CONV_SMALL_M": "0"}),
-                      ("no_persist", {"UT_PERSIST_LIMIT": "-1"})):
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
-                           env={**os.environ, **env})
-        assert r.returncode == 0, (name, r.stderr[-1500:])
-        line = [ln for ln in r.stdout.splitlines() if ln.startswith("FEAT")][0]
-        outs[name] = np.array([float(v) for v in line.split()[1:]])
-    for name, v in outs.items():
-        np.testing.assert_allclose(v, outs["default"], rtol=1e-6, err_msg=name)
+def test_conv_tile_shapes_agree(engine):
+    """The convolution dispatch picks its tile shape from the launch size alone (csrc/conv_igemm.hip::launch_conv_igemm):
+    the head's 3x3 / 1x1 convolutions run on 64x128 tiles up to 5 x 256 full-height tiles and on 128x128 tiles beyond
+    (S > 4551 samples), the backbone on 128x64 / 128x128 / the halo-patch kernel by channel count.  Every shape walks K
+    in the same order with the same MFMA, so a sample's result must not depend on which shape its batch selected: bit
+    for bit, big batch vs the same samples in small batches."""
+    s_big = 4800
+    n = 2 * s_big
+    g = torch.Generator(device=DEV)
+    g.manual_seed(3)
+    feat = torch.randn(n, 72, 6, 6, device=DEV, generator=g) * 0.3
+    k = torch.eye(3, device=DEV).repeat(n, 1, 1)
+    k[:, 0, 0] = k[:, 1, 1] = 100 + 60 * torch.rand(n, device=DEV, generator=g)
+    k[:, 0, 2] = k[:, 1, 2] = 47.5
+    x = torch.eye(4, device=DEV).repeat(n, 1, 1)
+    x[:, :3, 3] = torch.rand(n, 3, device=DEV, generator=g) * 0.2
+    hm = scenarios.hand_model_mm()
+    skel = _dev(np.stack([hm["joint_rotation_axes"], hm["joint_rest_positions"] * np.float32(0.001)])[None].astype(np.float32))
+
+    def run(lo, hi):
+        s = hi - lo
+        sr = torch.arange(0, 2 * s, 2, device=DEV)[:, None] + torch.tensor([0, 2], device=DEV)
+        engine.reset_memory()
+        return engine.fuse_temporal_regress(feat[2 * lo:2 * hi], k[2 * lo:2 * hi], x[2 * lo:2 * hi], sr,
+                                            torch.arange(s, device=DEV), torch.zeros(s, dtype=torch.bool, device=DEV),
+                                            (torch.arange(lo, hi, device=DEV) % 2), s, True, skel, _native.UT_MODE_KNOWN)[0].clone()
+    big = run(0, s_big)
+    assert torch.isfinite(big).all()
+    for lo, hi in ((0, 7), (1000, 1512), (s_big - 300, s_big)):
+        assert torch.equal(run(lo, hi), big[lo:hi]), (lo, hi)
+    engine.reset_memory()

@@ -11,6 +11,7 @@ The reference's pixels and weights are missing blobs, so the ref
 the reference by tests/test_oracle_pinning.py) fed the product's crops of seeded synthetic images, with the seeded
 synthetic weights; each side keeps its own temporal state, validity history and calibrated scale."""
 import pytest
+import torch
 
 from absolutetrack_amd import synth
 from oracle import checks
@@ -20,6 +21,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def weights():
+    torch.set_num_threads(min(torch.get_num_threads(), 16))   # the oracle's 4-crop forwards crawl when oversubscribed
     return synth.synthetic_state_dict(0)
 
 

@@ -1,6 +1,4 @@
-// Diagnostic entry (not part of libumetrack_hip.so): one stride-1 3x3 convolution through launch_conv_igemm
-// with the stamp buffer attached.
-#include <stdlib.h>
+// Diagnostic entry (not part of libumetrack_hip.so): one stride-1 3x3 convolution through launch_conv_igemm.
 
 #include "ut_kernels.h"
 extern "C" int conv_diag(const float* in, const float* w, const float* bias, const float* res, float* out, int n_img,
@@ -10,14 +8,8 @@ extern "C" int conv_diag(const float* in, const float* w, const float* bias, con
   c.n_img = n_img; c.H = hw; c.W = hw; c.cin = cin; c.Ho = hw; c.Wo = hw;
   c.cout_store = cout; c.cout_pad = (cout + 127) / 128 * 128; c.k_total = k_total; c.k_pad = k_total;
   c.cslice = cin % 32 == 0 ? 32 : cin; c.ksize = 3; c.stride = 1; c.pad = 1; c.relu = 1; c.out_nchw = 0;
-  c.num_cu = 256; c.persist_limit = 0; c.stagger = -1;
-#ifdef UT_STAMPS
-  c.stamps = stamps;
-#else
+  c.num_cu = 256; c.device = 0;
   (void)stamps;
-#endif
-  if (const char* e = getenv("UT_STAGGER")) c.stagger = atoi(e);
-  if (const char* e = getenv("UT_PERSIST_LIMIT")) c.persist_limit = atoi(e);
   static unsigned* cnt = nullptr;
   if (!cnt) (void)hipMalloc((void**)&cnt, 4);
   (void)hipMemsetAsync(cnt, 0, 4, 0);
