@@ -21,7 +21,7 @@ EXPORTS = (
     "ut_set_backbone_chunk", "ut_warp_crops", "ut_backbone", "ut_fuse_temporal_regress",
     "ut_reset_memory", "ut_get_memory", "ut_fk", "ut_gen_crop_cameras", "ut_gen_crop_matrices",
     "ut_resample_homography", "ut_keypoint_metrics", "ut_profile_begin", "ut_profile_end",
-    "ut_set_index_checks", "ut_poll_status",
+    "ut_set_index_checks", "ut_poll_status", "ut_warp_backbone",
 )
 
 UT_MODE_KNOWN, UT_MODE_UNKNOWN = 0, 1
@@ -60,6 +60,8 @@ def load_library() -> ctypes.CDLL:
     lib.ut_set_backbone_chunk.argtypes = [vp, i32]
     lib.ut_warp_crops.restype = i32
     lib.ut_warp_crops.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i32, i32, f32p, vp]
+    lib.ut_warp_backbone.restype = i32
+    lib.ut_warp_backbone.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i32, i32, f32p, vp]
     lib.ut_backbone.restype = i32
     lib.ut_backbone.argtypes = [vp, f32p, i32, f32p, vp]
     lib.ut_fuse_temporal_regress.restype = i32
@@ -73,7 +75,7 @@ def load_library() -> ctypes.CDLL:
     lib.ut_fk.argtypes = [vp, f32p, i32, f32p, i32, f32p, i32, vp, ctypes.c_float, i32, f32p, vp]
     lib.ut_gen_crop_cameras.restype = i32
     lib.ut_gen_crop_cameras.argtypes = [vp, vp, vp, f32p, f32p, i32, f32p, f32p, vp, vp, i32, i32, i32, i32, i32, i32,
-                                        i32, ctypes.c_double, vp, f32p, f32p, vp, vp, vp, vp]
+                                        i32, ctypes.c_double, vp, f32p, f32p, vp, vp, vp, f32p, vp]
     lib.ut_gen_crop_matrices.restype = i32
     lib.ut_gen_crop_matrices.argtypes = [vp, f32p, f32p, f32p, vp, i32, i32, i32, i32, ctypes.c_double, f32p, f32p, f32p,
                                          vp, vp]
@@ -173,7 +175,8 @@ def gen_crop_cameras(cam_params: torch.Tensor, camera_angles: torch.Tensor, hand
                      joint_limits: torch.Tensor, joint_angles: torch.Tensor, wrist_xf: torch.Tensor,
                      frame_idx: torch.Tensor, hand_idx: torch.Tensor, n_cams: int, src_wh: Tuple[int, int],
                      max_views: int = 2, min_vis: int = 19, crop_size: int = arch.CROP,
-                     focal_multiplier: float = 0.8, check_indices: bool = True) -> Dict[str, torch.Tensor]:
+                     focal_multiplier: float = 0.8, check_indices: bool = True,
+                     want_landmarks: bool = False) -> Dict[str, torch.Tensor]:
     """ut_gen_crop_cameras: crop cameras of n (frame, hand) label poses in one launch, padded to max_views.
     Returns crop_params [n,V,24] f64, intrinsics [n,V,3,3], extrinsics [n,V,4,4], cam_index [n,V] i32,
     n_views [n] i32, status [n] i32.  All tensors on one HIP device; no CPU fallback."""
@@ -205,13 +208,15 @@ def gen_crop_cameras(cam_params: torch.Tensor, camera_angles: torch.Tensor, hand
            "cam_index": torch.empty(n, max_views, dtype=torch.int32, device=d),
            "n_views": torch.empty(n, dtype=torch.int32, device=d),
            "status": torch.empty(n, dtype=torch.int32, device=d)}
+    if want_landmarks:
+        out["landmarks"] = torch.empty(n, arch.N_LANDMARKS, 3, dtype=torch.float32, device=d)
     with torch.cuda.device(d):
         rc = lib.ut_gen_crop_cameras(None, _ptr(cam_params), _ptr(camera_angles), _ptr(hand_model), _ptr(joint_limits),
                                      hand_model.shape[0], _ptr(joint_angles), _ptr(wrist_xf), _ptr(frame_idx),
                                      _ptr(hand_idx), n, n_cams, max_views, min_vis, int(src_wh[0]), int(src_wh[1]),
                                      crop_size, ctypes.c_double(focal_multiplier), _ptr(out["crop_params"]),
                                      _ptr(out["intrinsics"]), _ptr(out["extrinsics"]), _ptr(out["cam_index"]),
-                                     _ptr(out["n_views"]), _ptr(out["status"]), _stream(d))
+                                     _ptr(out["n_views"]), _ptr(out["status"]), _ptr(out.get("landmarks")), _stream(d))
     if rc != 0:
         raise RuntimeError(f"ut_gen_crop_cameras failed ({rc}): {lib.ut_last_error(None).decode()}")
     return out
@@ -377,6 +382,27 @@ class HipEngine:
         self._check(self.lib.ut_warp_crops(self._h, _ptr(src_u8), src_u8.shape[0], src_u8.shape[1], src_u8.shape[2],
                                            _ptr(cam_params), _ptr(crop_params), _ptr(src_index), n, mode, _ptr(out),
                                            _stream(d)), "ut_warp_crops")
+        return out
+
+    def warp_backbone(self, src_u8: torch.Tensor, cam_params: torch.Tensor, crop_params: torch.Tensor,
+                      src_index: torch.Tensor, mode: int = UT_REMAP_CV2_FIXED,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """ut_warp_backbone: resample + backbone with the crops kept in the handle's workspace (u8 in cv2 mode)."""
+        d = self.device
+        src_u8 = _need(src_u8, torch.uint8, d, "src")
+        if src_u8.dim() != 3:
+            raise ValueError("src must be [n_images, H, W] uint8")
+        cam_params = _need(cam_params, torch.float64, d, "cam_params")
+        crop_params = _need(crop_params, torch.float64, d, "crop_params")
+        src_index = _need(src_index, torch.int32, d, "src_index")
+        n = crop_params.shape[0]
+        if cam_params.shape != (src_u8.shape[0], 32) or crop_params.shape != (n, 24) or src_index.shape != (n,):
+            raise ValueError("bad cam_params / crop_params / src_index shape")
+        if out is None:
+            out = torch.empty(n, arch.FEAT_CH, arch.FEAT_HW, arch.FEAT_HW, dtype=torch.float32, device=d)
+        self._check(self.lib.ut_warp_backbone(self._h, _ptr(src_u8), src_u8.shape[0], src_u8.shape[1], src_u8.shape[2],
+                                              _ptr(cam_params), _ptr(crop_params), _ptr(src_index), n, mode, _ptr(out),
+                                              _stream(d)), "ut_warp_backbone")
         return out
 
     def backbone(self, crops: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

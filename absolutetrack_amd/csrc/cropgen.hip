@@ -145,6 +145,8 @@ __global__ __launch_bounds__(64) void cropgen_kernel(CropGenArgs g) {
   float ja[22];
   for (int k = 0; k < 22; ++k) ja[k] = g.joint_angles[(size_t)s * 22 + k];
   skin_landmarks_dev(hm, ja, wrist, pts);
+  if (g.landmarks)      // the label pose's landmarks = landmarks_from_hand_pose(hand_model, pose, hand_idx), same FK as ut_fk
+    for (int k = 0; k < 63; ++k) g.landmarks[(size_t)s * 63 + k] = pts[k];
   const float* lim = g.joint_limits + (size_t)(g.n_models == 1 ? 0 : s) * 44;
   for (int k = 0; k < 22; ++k) ja[k] = lim[2 * k] * 0.5f + lim[2 * k + 1] * (1.0f - 0.5f);   // perspective_crop.py:19-24
   skin_landmarks_dev(hm, ja, wrist, pts + 63);

@@ -4,6 +4,9 @@
 // One workgroup = one crop x 4 pooled rows; the 10 x 96 input rows it needs are staged in LDS
 // with a zero halo.  One thread = one pooled pixel x 4 output channels (a 16-byte NHWC store;
 // 8 threads cover the 32 channels = one 128-byte line per pixel).
+// The crops arrive as fp32 in [0,1] (the public entry, like the reference's tensor) or as the resampler's exact u8
+// grey levels (the fused resample -> backbone path: 4x fewer bytes between the two kernels); (float)u8 / 255.0f is
+// the same value the resampler's fp32 output holds, bit for bit.
 #include "ut_kernels.h"
 
 namespace ut {
@@ -13,7 +16,11 @@ constexpr int ROWS_PER_WG = 4;                 // pooled rows per workgroup
 constexpr int IN_ROWS = 2 * ROWS_PER_WG + 2;   // input rows incl. halo
 constexpr int IN_COLS = CROP + 2;
 
-__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ crops,
+__device__ __forceinline__ float stem_px(float v) { return v; }
+__device__ __forceinline__ float stem_px(uint8_t v) { return (float)v / 255.0f; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_kernel(const T* __restrict__ crops,
                                                    const float* __restrict__ w,
                                                    const float* __restrict__ bias,
                                                    float* __restrict__ out, int n) {
@@ -21,12 +28,12 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ cro
   __shared__ float ws[STEM_C * 9 + STEM_C];
   const int img = blockIdx.y;
   const int prow0 = blockIdx.x * ROWS_PER_WG;
-  const float* src = crops + (size_t)img * CROP * CROP;
+  const T* src = crops + (size_t)img * CROP * CROP;
   for (int i = threadIdx.x; i < STEM_C * 9 + STEM_C; i += 256) ws[i] = i < STEM_C * 9 ? w[i] : bias[i - STEM_C * 9];
   for (int i = threadIdx.x; i < IN_ROWS * IN_COLS; i += 256) {
     int r = i / IN_COLS, c = i - r * IN_COLS;
     int y = 2 * prow0 - 1 + r, x = c - 1;
-    tile[r][c] = (y >= 0 && y < CROP && x >= 0 && x < CROP) ? src[y * CROP + x] : 0.f;
+    tile[r][c] = (y >= 0 && y < CROP && x >= 0 && x < CROP) ? stem_px(src[y * CROP + x]) : 0.f;
   }
   __syncthreads();
   // 4 rows x 48 pooled pixels x 8 channel groups = 1536 work items, 6 per thread.  A thread's channel group
@@ -72,18 +79,25 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ cro
   }
 }
 
-hipError_t launch_stem(const float* crops, const float* w, const float* bias, float* out, int n,
-                       hipStream_t s) {
+template <typename T>
+static hipError_t launch_stem_t(const T* crops, const float* w, const float* bias, float* out, int n, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   // grid.y is limited to 65535: split very large batches
   for (int done = 0; done < n;) {
     int cnt = n - done < 32768 ? n - done : 32768;
-    hipLaunchKernelGGL(stem_kernel, dim3(POOLED / ROWS_PER_WG, cnt), dim3(256), 0, s,
+    hipLaunchKernelGGL(stem_kernel<T>, dim3(POOLED / ROWS_PER_WG, cnt), dim3(256), 0, s,
                        crops + (size_t)done * CROP * CROP, w, bias,
                        out + (size_t)done * POOLED * POOLED * STEM_C, cnt);
     done += cnt;
   }
   return hipGetLastError();
+}
+
+hipError_t launch_stem(const float* crops, const float* w, const float* bias, float* out, int n, hipStream_t s) {
+  return launch_stem_t(crops, w, bias, out, n, s);
+}
+hipError_t launch_stem_u8(const uint8_t* crops, const float* w, const float* bias, float* out, int n, hipStream_t s) {
+  return launch_stem_t(crops, w, bias, out, n, s);
 }
 
 }  // namespace ut

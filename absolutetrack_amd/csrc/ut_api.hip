@@ -65,6 +65,9 @@ struct ut_context {
   int chunk = kDefaultChunk;
   int ws_crops = 0;       // phase-A capacity (crops)
   float *bufX = nullptr, *bufH = nullptr, *bufY = nullptr, *bufD = nullptr;
+  // fused resample -> backbone: the crops between the two kernels (u8 grey levels, or fp32 in UT_REMAP_FLOAT mode)
+  size_t crops_ws_bytes = 0;
+  void* crops_ws = nullptr;
   int wsb_crops = 0;      // phase-B capacity (crops)
   float *bufL2 = nullptr, *bufP = nullptr, *bufQ = nullptr, *bufBH = nullptr, *bufBD = nullptr;
   // head workspace
@@ -537,6 +540,15 @@ int ut_reserve(ut_handle h, int max_crops, int max_samples, int max_slots) {
   if (cb > 0 && (rc = ensure_phase_b_ws(h, cb))) return rc;
   if (max_samples > 0 && (rc = ensure_head_ws(h, max_samples, max_samples))) return rc;
   if (max_slots > 0 && (rc = ensure_slots(h, max_slots, 0))) return rc;
+  const size_t crops_need = (size_t)(max_crops > 0 ? max_crops : 0) * 96 * 96 * sizeof(float);
+  if (crops_need > h->crops_ws_bytes) {
+    HIPCHK(h, hipDeviceSynchronize());
+    dev_free(h, h->crops_ws);
+    h->crops_ws = nullptr; h->crops_ws_bytes = 0;
+    float* pnew = nullptr;
+    if ((rc = dev_alloc(h, &pnew, crops_need / 4))) return rc;
+    h->crops_ws = pnew; h->crops_ws_bytes = crops_need;
+  }
   return UT_OK;
 }
 
@@ -560,7 +572,7 @@ int ut_warp_crops(ut_handle h, const uint8_t* src, int n_src_images, int src_h, 
   DeviceScope scope(dev);
   if (scope.err != hipSuccess) return fail(h, UT_E_HIP, "hipSetDevice", scope.err);
   HIPCHK(h, ut::launch_warp(src, n_src_images, src_h, src_w, cam_params, crop_params, src_index, n_crops, remap_mode,
-                            out, st_dev, s));
+                            out, nullptr, st_dev, s));
   if (mode == UT_CHECK_SYNC) {
     int sticky = 0, call = 0, rc = read_status(h, st_dev, st_host, s, &sticky, &call);
     if (rc) return rc;
@@ -573,12 +585,8 @@ int ut_warp_crops(ut_handle h, const uint8_t* src, int n_src_images, int src_h, 
   return UT_OK;
 }
 
-int ut_backbone(ut_handle h, const float* crops, int n_crops, float* feat, void* stream) {
-  if (!h) return UT_E_INVALID;
-  if (n_crops == 0) return UT_OK;
-  if (!crops || !feat || n_crops < 0) return fail(h, UT_E_INVALID, "ut_backbone: bad argument");
-  ON_DEVICE_OF(h);
-  hipStream_t s = (hipStream_t)stream;
+// stem .. projection over crops given as fp32 (crops) or as u8 grey levels (crops_u8)
+static int run_backbone(ut_handle h, const float* crops, const uint8_t* crops_u8, int n_crops, float* feat, hipStream_t s) {
   int rc;
   const int chunk = n_crops < h->chunk ? n_crops : h->chunk;
   if ((rc = ensure_backbone_ws(h, chunk))) return rc;
@@ -590,7 +598,9 @@ int ut_backbone(ut_handle h, const float* crops, int n_crops, float* feat, void*
     // ---- phase A: stem + layer1 (48x48x32) + layer2 (24x24x64), `chunk` crops per pass
     for (int done = 0; done < nb; done += chunk) {
       const int n = nb - done < chunk ? nb - done : chunk;
-      HIPCHK(h, ut::launch_stem(crops + (size_t)(base + done) * 96 * 96, h->stem_w, h->stem_b, h->bufX, n, s));
+      const size_t first = (size_t)(base + done) * 96 * 96;
+      if (crops_u8) HIPCHK(h, ut::launch_stem_u8(crops_u8 + first, h->stem_w, h->stem_b, h->bufX, n, s));
+      else HIPCHK(h, ut::launch_stem(crops + first, h->stem_w, h->stem_b, h->bufX, n, s));
       float *x = h->bufX, *y = h->bufY;
       int hw = 48;
       for (int b = 0; b < 5; ++b) {
@@ -614,6 +624,50 @@ int ut_backbone(ut_handle h, const float* crops, int n_crops, float* feat, void*
     if ((rc = run_conv(h, h->proj, x, nullptr, feat + (size_t)base * 72 * 36, nb, 6, 6, false, true, s))) return rc;
   }
   return UT_OK;
+}
+
+int ut_backbone(ut_handle h, const float* crops, int n_crops, float* feat, void* stream) {
+  if (!h) return UT_E_INVALID;
+  if (n_crops == 0) return UT_OK;
+  if (!crops || !feat || n_crops < 0) return fail(h, UT_E_INVALID, "ut_backbone: bad argument");
+  ON_DEVICE_OF(h);
+  return run_backbone(h, crops, nullptr, n_crops, feat, (hipStream_t)stream);
+}
+
+int ut_warp_backbone(ut_handle h, const uint8_t* src, int n_src_images, int src_h, int src_w, const double* cam_params,
+                     const double* crop_params, const int32_t* src_index, int n_crops, int remap_mode, float* feat,
+                     void* stream) {
+  if (!h) return UT_E_INVALID;
+  if (n_crops == 0) return UT_OK;
+  if (!src || !cam_params || !crop_params || !src_index || !feat || n_crops < 0 || src_h <= 0 || src_w <= 0 ||
+      n_src_images <= 0 || (remap_mode != UT_REMAP_CV2_FIXED && remap_mode != UT_REMAP_FLOAT))
+    return fail(h, UT_E_INVALID, "ut_warp_backbone: bad argument");
+  ON_DEVICE_OF(h);
+  hipStream_t s = (hipStream_t)stream;
+  const bool u8 = remap_mode == UT_REMAP_CV2_FIXED;
+  const size_t need = (size_t)n_crops * 96 * 96 * (u8 ? 1 : sizeof(float));
+  if (need > h->crops_ws_bytes) {
+    HIPCHK(h, hipDeviceSynchronize());
+    dev_free(h, h->crops_ws);
+    h->crops_ws = nullptr; h->crops_ws_bytes = 0;
+    float* pnew = nullptr;
+    int rc0 = dev_alloc(h, &pnew, (need + 3) / 4);
+    if (rc0) return rc0;
+    h->crops_ws = pnew; h->crops_ws_bytes = need;
+  }
+  HIPCHK(h, ut::launch_warp(src, n_src_images, src_h, src_w, cam_params, crop_params, src_index, n_crops, remap_mode,
+                            u8 ? nullptr : (float*)h->crops_ws, u8 ? (uint8_t*)h->crops_ws : nullptr, h->status, s));
+  if (h->check_mode == UT_CHECK_SYNC) {
+    int sticky = 0, call = 0, rc = read_status(h, h->status, h->status_host, s, &sticky, &call);
+    if (rc) return rc;
+    if (sticky & ut::UT_STATUS_ERRORS) {
+      char buf[160];
+      snprintf(buf, sizeof buf, "ut_warp_backbone: %s", status_message(sticky));
+      return fail(h, UT_E_INVALID, buf);
+    }
+  }
+  return run_backbone(h, u8 ? nullptr : (const float*)h->crops_ws, u8 ? (const uint8_t*)h->crops_ws : nullptr, n_crops,
+                      feat, s);
 }
 
 int ut_fuse_temporal_regress(ut_handle h, const float* feat, const float* intrinsics, const float* extrinsics,
@@ -729,7 +783,7 @@ int ut_gen_crop_cameras(ut_handle h, const double* cam_params, const double* cam
                         const int32_t* frame_idx, const int64_t* hand_idx, int n, int n_cams, int max_views, int min_vis,
                         int src_w, int src_h, int crop_size, double focal_multiplier, double* crop_params,
                         float* intrinsics, float* extrinsics, int32_t* cam_index, int32_t* n_views, int32_t* status,
-                        void* stream) {
+                        float* landmarks, void* stream) {
   if (n == 0) return UT_OK;
   if (!cam_params || !camera_angles || !hand_model || !joint_limits || !joint_angles || !wrist_xf || !frame_idx ||
       !hand_idx || !crop_params || !intrinsics || !extrinsics || !cam_index || !n_views || !status || n < 0 ||
@@ -742,7 +796,7 @@ int ut_gen_crop_cameras(ut_handle h, const double* cam_params, const double* cam
   g.n = n; g.n_models = n_models; g.n_cams = n_cams; g.max_views = max_views; g.min_vis = min_vis;
   g.src_w = src_w; g.src_h = src_h; g.crop_size = crop_size; g.focal_multiplier = focal_multiplier;
   g.crop_params = crop_params; g.intrinsics = intrinsics; g.extrinsics = extrinsics; g.cam_index = cam_index;
-  g.n_views = n_views; g.status = status;
+  g.n_views = n_views; g.status = status; g.landmarks = landmarks;
   HIPCHK(h, ut::launch_cropgen(g, (hipStream_t)stream));
   return UT_OK;
 }

@@ -40,6 +40,8 @@ hipError_t launch_conv_patch(const ConvLaunch& c, hipStream_t s);
 // stem: conv3x3(1->32,pad 1)+BN+ReLU+maxpool2 ; crops [n,96,96] -> NHWC [n,48,48,32]
 hipError_t launch_stem(const float* crops, const float* w /*[32][9]*/, const float* bias /*[32]*/,
                        float* out, int n, hipStream_t s);
+// the same on the resampler's u8 grey levels (value / 255 on load)
+hipError_t launch_stem_u8(const uint8_t* crops, const float* w, const float* bias, float* out, int n, hipStream_t s);
 
 struct HeadBuffers {
   // workspace, all NHWC over the 6x6 map: [S,36,C]
@@ -127,6 +129,7 @@ struct CropGenArgs {
   int32_t* cam_index;           // [n,max_views]  (-1 = unused slot)
   int32_t* n_views;             // [n]
   int32_t* status;              // [n] 0 ok, 1 = "Unable to create crop camera"
+  float* landmarks;             // optional [n,21,3]: world landmarks of the label pose (mm)
 };
 hipError_t launch_cropgen(const CropGenArgs& g, hipStream_t s);
 
@@ -152,9 +155,10 @@ hipError_t launch_keypoint_metrics(const float* gt, const float* tracked, const 
 
 hipError_t launch_mem_export(const float* mem /*[slots,36,18]*/, float* out /*[slots,18,36]*/, int slots, hipStream_t s);
 
-// status: device word; a crop whose src_index is outside [0, n_src) is written as zeros and sets UT_BAD_SRC_INDEX
+// status: device word; a crop whose src_index is outside [0, n_src) is written as zeros and sets UT_BAD_SRC_INDEX.
+// out_u8 != NULL (mode 0 only): write the grey levels as u8 instead of out = level / 255.
 hipError_t launch_warp(const uint8_t* src, int n_src, int src_h, int src_w, const double* cam,
                        const double* crop, const int32_t* src_index, int n_crops, int mode, float* out,
-                       int* status, hipStream_t s);
+                       uint8_t* out_u8, int* status, hipStream_t s);
 
 }  // namespace ut

@@ -16,17 +16,20 @@ __device__ inline int tap(const uint8_t* img, int h, int w, int x, int y) {
   return (x >= 0 && x < w && y >= 0 && y < h) ? (int)img[y * w + x] : 0;
 }
 
+template <bool U8>
 __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ src, int src_h, int src_w,
                                                    const double* __restrict__ cam,
                                                    const double* __restrict__ crop,
                                                    const int32_t* __restrict__ src_index, int n_src, int mode,
-                                                   float* __restrict__ out, int* __restrict__ status) {
+                                                   float* __restrict__ out, uint8_t* __restrict__ out_u8,
+                                                   int* __restrict__ status) {
   const int ci = blockIdx.y;
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= CROP_PX) return;
   const int si = src_index[ci];
   if (si < 0 || si >= n_src) {      // the reference would raise IndexError on views[cam_idx] (lib/tracker/tracker.py:330)
-    out[(size_t)ci * CROP_PX + pix] = 0.f;
+    if constexpr (U8) out_u8[(size_t)ci * CROP_PX + pix] = 0;
+    else out[(size_t)ci * CROP_PX + pix] = 0.f;
     if (pix == 0) atomicOr(status, UT_BAD_SRC_INDEX);
     return;
   }
@@ -91,15 +94,24 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ s
                (double)tap(img, src_h, src_w, ix + 1, iy + 1) * (double)(fx * fy);
     result = (float)v;
   }
-  out[(size_t)ci * CROP_PX + pix] = result / 255.0f;
+  if constexpr (U8) out_u8[(size_t)ci * CROP_PX + pix] = (uint8_t)result;   // mode 0 only: an exact grey level
+  else out[(size_t)ci * CROP_PX + pix] = result / 255.0f;
 }
 
 hipError_t launch_warp(const uint8_t* src, int n_src, int src_h, int src_w, const double* cam, const double* crop,
-                       const int32_t* src_index, int n_crops, int mode, float* out, int* status, hipStream_t s) {
+                       const int32_t* src_index, int n_crops, int mode, float* out, uint8_t* out_u8, int* status,
+                       hipStream_t s) {
+  if (out_u8 && mode != 0) return hipErrorInvalidValue;   // only OpenCV's 8-bit arithmetic yields exact grey levels
   for (int done = 0; done < n_crops;) {
     int cnt = n_crops - done < 32768 ? n_crops - done : 32768;
-    hipLaunchKernelGGL(warp_kernel, dim3(CROP_PX / 256, cnt), dim3(256), 0, s, src, src_h, src_w, cam,
-                       crop + (size_t)done * 24, src_index + done, n_src, mode, out + (size_t)done * CROP_PX, status);
+    if (out_u8)
+      hipLaunchKernelGGL(warp_kernel<true>, dim3(CROP_PX / 256, cnt), dim3(256), 0, s, src, src_h, src_w, cam,
+                         crop + (size_t)done * 24, src_index + done, n_src, mode, (float*)nullptr,
+                         out_u8 + (size_t)done * CROP_PX, status);
+    else
+      hipLaunchKernelGGL(warp_kernel<false>, dim3(CROP_PX / 256, cnt), dim3(256), 0, s, src, src_h, src_w, cam,
+                         crop + (size_t)done * 24, src_index + done, n_src, mode, out + (size_t)done * CROP_PX,
+                         (uint8_t*)nullptr, status);
     done += cnt;
   }
   return hipGetLastError();

@@ -244,8 +244,11 @@ class HotPath:
     records are consumed - raises IndexError for it."""
 
     def __init__(self, engine: _native.HipEngine, hand_model_mm: HandModel, known_skeleton: bool = True,
-                 remap_mode: int = _native.UT_REMAP_CV2_FIXED):
+                 remap_mode: int = _native.UT_REMAP_CV2_FIXED, keep_crops: bool = False):
+        """keep_crops: materialise the fp32 crop tensor (ut_warp_crops + ut_backbone, the crops are then in
+        `self.crops`) instead of the fused ut_warp_backbone, whose crops stay u8 in the engine's workspace."""
         self.engine = engine
+        self.keep_crops = keep_crops
         engine.set_index_checks(deferred=True)
         self.mode = _native.UT_MODE_KNOWN if known_skeleton else _native.UT_MODE_UNKNOWN
         self.remap_mode = remap_mode
@@ -263,7 +266,7 @@ class HotPath:
         key = (b.n_crops, b.n_samples)
         if self._bufs is None or self._bufs[0] != key:
             dev = self.engine.device
-            self._bufs = (key, torch.empty(b.n_crops, arch.CROP, arch.CROP, device=dev),
+            self._bufs = (key, torch.empty(b.n_crops if self.keep_crops else 0, arch.CROP, arch.CROP, device=dev),
                           torch.empty(b.n_crops, arch.FEAT_CH, arch.FEAT_HW, arch.FEAT_HW, device=dev),
                           torch.empty(b.n_samples, RECORD, device=dev))
             self.engine.reserve(b.n_crops, b.n_samples, b.n_slots)
@@ -273,8 +276,11 @@ class HotPath:
         """[S,123] records (pose record | keypoints in mm)."""
         eng = self.engine
         crops, feat, rec = self._buffers(b)
-        eng.warp_crops(b.src, b.cam_params, b.crop_params, b.src_index, self.remap_mode, out=crops)
-        eng.backbone(crops, out=feat)
+        if self.keep_crops:
+            eng.warp_crops(b.src, b.cam_params, b.crop_params, b.src_index, self.remap_mode, out=crops)
+            eng.backbone(crops, out=feat)
+        else:
+            eng.warp_backbone(b.src, b.cam_params, b.crop_params, b.src_index, self.remap_mode, out=feat)
         s = b.n_samples
         pose, _ = eng.fuse_temporal_regress(feat, b.intrinsics, b.extrinsics, b.sample_range, b.memory_idx,
                                             b.use_memory, b.hand_idx, b.n_slots, b.all_multiview, self.skel,

@@ -103,6 +103,15 @@ int ut_warp_crops(ut_handle h, const uint8_t* src, int n_src_images, int src_h, 
  *  crops f32 [n_crops,96,96] -> feat f32 [n_crops,72,6,6] (NCHW like the reference). */
 int ut_backbone(ut_handle h, const float* crops, int n_crops, float* feat, void* stream);
 
+/* ut_warp_crops followed by ut_backbone without materialising the fp32 crop tensor: the resampled crops stay in
+ * the handle's workspace - as the exact u8 grey levels OpenCV's 8-bit remap produces in UT_REMAP_CV2_FIXED mode
+ * (lib/tracker/tracker.py:87 returns u8, :332 divides by 255: the stem applies the /255 on load, same bits), as
+ * fp32 in UT_REMAP_FLOAT mode.  Arguments as for the two calls it replaces (lib/tracker/tracker.py:61-89,332 +
+ * lib/models/umetrack_model.py:127-129). */
+int ut_warp_backbone(ut_handle h, const uint8_t* src, int n_src_images, int src_h, int src_w,
+                     const double* cam_params, const double* crop_params, const int32_t* src_index,
+                     int n_crops, int remap_mode, float* feat, void* stream);
+
 /* Everything after the backbone in UmeTrackModel.regress_pose_use_skeleton /
  * regress_pose_pred_skel_scale (lib/models/umetrack_model.py:131-242): single-view xfs, FTL,
  * 2-view fusion, temporal ConvRNN (state kept in the handle, lib/models/temporal.py:93-139),
@@ -158,14 +167,18 @@ int ut_fk(ut_handle h, const float* hand_model, int n_models, const float* joint
  *  crop_params f64 [n,max_views,24] (rows as for ut_warp_crops), intrinsics f32 [n,max_views,3,3],
  *  extrinsics f32 [n,max_views,4,4] (world->eye, translation in metres), cam_index i32 [n,max_views]
  *  (-1 = unused), n_views i32 [n], status i32 [n] (1 where the reference raises "Unable to create
- *  crop camera", lib/common/crop.py:25-26).  Stateless: h may be NULL. */
+ *  crop camera", lib/common/crop.py:25-26); landmarks f32 [n,21,3] (optional, may be NULL): the world
+ *  landmarks of each pose, i.e. landmarks_from_hand_pose(hand_model, pose, hand_idx) of
+ *  lib/tracker/perspective_crop.py:40-51 (the crop points' first 21; same arithmetic as ut_fk).
+ *  Stateless: h may be NULL. */
 int ut_gen_crop_cameras(ut_handle h, const double* cam_params, const double* camera_angles,
                         const float* hand_model, const float* joint_limits, int n_models,
                         const float* joint_angles, const float* wrist_xf, const int32_t* frame_idx,
                         const int64_t* hand_idx, int n, int n_cams, int max_views, int min_vis,
                         int src_w, int src_h, int crop_size, double focal_multiplier,
                         double* crop_params, float* intrinsics, float* extrinsics,
-                        int32_t* cam_index, int32_t* n_views, int32_t* status, void* stream);
+                        int32_t* cam_index, int32_t* n_views, int32_t* status, float* landmarks,
+                        void* stream);
 
 /* torch_data path, lib/batched_dataset/data_transform.py:147-212 (_gen_crop_matrices) for every
  * (frame, view) of a batch in one launch.

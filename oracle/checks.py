@@ -68,7 +68,7 @@ def run_small_end_to_end(sd_np, n_frames: int = 2, device: str = "cuda:0", known
     try:
         plan = pipeline.crop_plan_from_labels(lab, hm, frame_ids)
         batch = pipeline.make_batch(plan, torch.from_numpy(frames.reshape(-1, 480, 636)), device)
-        hot = pipeline.HotPath(eng, hm, known_skeleton=known)
+        hot = pipeline.HotPath(eng, hm, known_skeleton=known, keep_crops=True)
         rec = hot.step(batch).cpu().numpy()
         hot.check()
         gpu_crops = hot._bufs[1].cpu().numpy()

@@ -294,6 +294,34 @@ def test_warp_matches_oracle(engine, mode):
         assert diff.max() < 1e-4
 
 
+@pytest.mark.parametrize("mode", [_native.UT_REMAP_CV2_FIXED, _native.UT_REMAP_FLOAT])
+def test_fused_resample_backbone_equals_the_two_calls(engine, mode):
+    """ut_warp_backbone (crops kept in the workspace: u8 grey levels in cv2 mode, fp32 in float mode) gives the
+    features of ut_warp_crops + ut_backbone bit for bit; a bad src_index is refused the same way."""
+    from absolutetrack_amd import geometry
+    lab = scenarios.labels()
+    hm = scenarios.hand_model_mm()
+    frames = synth.synthetic_frames(2, seed=6)
+    cams_all, crops_all, src_idx = [], [], []
+    for f, fi in enumerate((30, 310)):
+        cams = _rec00_cameras(lab, fi)
+        cams_all += [geometry.pack_source_camera(c["f"], c["c"], c["k"], c["T"]) for c in cams]
+        for hand in (0, 1):
+            cc = ref_camera.gen_crop_cameras(cams, lab["camera_angles"], hm, lab["joint_angles"][fi, hand],
+                                             lab["wrist_transforms"][fi, hand], hand)
+            for ci, crop in cc.items():
+                crops_all.append(geometry.pack_crop_camera(crop["f"], crop["c"], crop["T"]))
+                src_idx.append(f * 4 + ci)
+    src, cam, crop = _dev(frames.reshape(-1, 480, 636)), _dev(np.stack(cams_all)), _dev(np.stack(crops_all))
+    idx = _dev(np.array(src_idx, np.int32))
+    crops = engine.warp_crops(src, cam, crop, idx, mode)
+    want = engine.backbone(crops)
+    got = engine.warp_backbone(src, cam, crop, idx, mode)
+    assert got.shape == want.shape == (8, 72, 6, 6) and torch.equal(got, want)
+    with pytest.raises(IndexError, match="src_index"):
+        engine.warp_backbone(src, cam, crop, _dev(np.array([0, 1, 2, 3, 4, 5, 6, 8], np.int32)), mode)
+
+
 def _head_inputs(engine, n_samples=3, seed=2):
     n = 2 * n_samples
     g = torch.Generator(device=DEV)

@@ -32,7 +32,8 @@ for spec in sys.argv[5:]:
     so = f"/tmp/libconvab_{name}.so"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w", *flags,
                            "-o", so, os.path.join(ROOT, src) if not os.path.isabs(src) else src,
-                           os.path.join(CSRC, "conv_patch.hip"), os.path.join(ROOT, "tools", "diag", "conv_diag_entry.hip"),
+                           os.path.join(CSRC, "conv_patch.hip"), os.path.join(ROOT, "tools", "diag", "conv_ws_experiment.hip"),
+                           os.path.join(ROOT, "tools", "diag", "conv_diag_entry.hip"),
                            "-I", CSRC])
     lib = ctypes.CDLL(so)
     lib.conv_diag.restype = ctypes.c_int

@@ -1,6 +1,9 @@
 // Diagnostic entry (not part of libumetrack_hip.so): one stride-1 3x3 convolution through launch_conv_igemm.
 
 #include "ut_kernels.h"
+#ifdef DIAG_WS
+namespace ut { hipError_t launch_conv_ws(const ConvLaunch& c, hipStream_t s); }
+#endif
 extern "C" int conv_diag(const float* in, const float* w, const float* bias, const float* res, float* out, int n_img,
                          int hw, int cin, int cout, int k_total, long long* stamps) {
   ut::ConvLaunch c{};
@@ -14,5 +17,9 @@ extern "C" int conv_diag(const float* in, const float* w, const float* bias, con
   if (!cnt) (void)hipMalloc((void**)&cnt, 4);
   (void)hipMemsetAsync(cnt, 0, 4, 0);
   c.tile_counter = cnt;
+#ifdef DIAG_WS
+  return (int)ut::launch_conv_ws(c, 0);
+#else
   return (int)ut::launch_conv_igemm(c, 0);
+#endif
 }
