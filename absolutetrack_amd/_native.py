@@ -21,7 +21,7 @@ EXPORTS = (
     "ut_set_backbone_chunk", "ut_warp_crops", "ut_backbone", "ut_fuse_temporal_regress",
     "ut_reset_memory", "ut_get_memory", "ut_fk", "ut_gen_crop_cameras", "ut_gen_crop_matrices",
     "ut_resample_homography", "ut_keypoint_metrics", "ut_profile_begin", "ut_profile_end",
-    "ut_set_index_checks", "ut_poll_status", "ut_warp_backbone",
+    "ut_set_index_checks", "ut_poll_status", "ut_warp_backbone", "ut_set_latency_mode",
 )
 
 UT_MODE_KNOWN, UT_MODE_UNKNOWN = 0, 1
@@ -90,6 +90,8 @@ def load_library() -> ctypes.CDLL:
                                    ctypes.POINTER(ctypes.c_double)]
     lib.ut_set_index_checks.restype = i32
     lib.ut_set_index_checks.argtypes = [vp, i32]
+    lib.ut_set_latency_mode.restype = i32
+    lib.ut_set_latency_mode.argtypes = [vp, i32]
     lib.ut_poll_status.restype = i32
     lib.ut_poll_status.argtypes = [vp, vp]
     _lib = lib
@@ -353,6 +355,11 @@ class HipEngine:
         the device and `poll_status()` raises for it later."""
         self._check(self.lib.ut_set_index_checks(self._h, UT_CHECK_DEFERRED if deferred else UT_CHECK_SYNC),
                     "ut_set_index_checks")
+
+    def set_latency_mode(self, on: bool):
+        """Few-crop launches split K across workgroups (per-frame tracking); results then agree with the default mode to
+        fp32 rounding instead of bit for bit.  Off by default."""
+        self._check(self.lib.ut_set_latency_mode(self._h, int(bool(on))), "ut_set_latency_mode")
 
     def poll_status(self):
         self._check(self.lib.ut_poll_status(self._h, _stream(self.device)), "ut_poll_status")

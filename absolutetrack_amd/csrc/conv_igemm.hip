@@ -82,7 +82,12 @@ __device__ __forceinline__ int fast_div(int n, int d, float inv_d) {
   return q;
 }
 
-template <int BM, int BN, int WR, int WC, bool NCHW = false, bool C32 = false>
+// SPLITK (latency mode, launches of a few crops): the tile queue holds p.splits entries per output tile, entry
+// (split s, tile t) walks the chunks [s, s+1) * n_chunks of K and stores its partial sums (no bias, residual or ReLU:
+// the host passes a zero bias and no residual) to slab s of p.out [splits][M][cout_store]; splitk_finish_kernel adds
+// the slabs in a fixed order and applies the epilogue.  Not used by the throughput path: its kernels are the
+// SPLITK = false instantiations, unchanged.
+template <int BM, int BN, int WR, int WC, bool NCHW = false, bool C32 = false, bool SPLITK = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int tiles_n, int n_tiles, int stagger) {
   static_assert(WR * WC == 4, "4 waves per workgroup");
   constexpr int MI = BM / WR / 32;   // 32x32 accumulator tiles per wave along M
@@ -111,7 +116,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
   const int hw = p.Ho * p.Wo;
   const float inv_hw = 1.0f / (float)hw, inv_wo = 1.0f / (float)p.Wo;
   const int taps = p.ksize * p.ksize;
-  const int n_chunks = p.k_pad / BK;
+  const int n_splits = SPLITK ? p.splits : 1;
+  const int real_tiles = SPLITK ? n_tiles / n_splits : n_tiles;        // output tiles (n_tiles counts queue entries)
+  const int n_chunks = p.k_pad / BK / n_splits;                        // chunks walked per queue entry
+  // queue entry -> (split, tile row, tile column); entries past the end get a tile row beyond M (every row then
+  // fails the range checks and the requests return zeros, as for SPLITK = false where that follows from the division)
+#define UT_DECOMP(TILE)                                                                              \
+    const int sp_ = SPLITK ? (TILE) / real_tiles : 0;                                                \
+    const int t_ = (TILE) - sp_ * real_tiles;                                                        \
+    const int tq_ = t_ / tiles_n;                                                                    \
+    const int tm_ = (!SPLITK || (TILE) < n_tiles) ? tq_ : (1 << 20), tn_ = t_ - tq_ * tiles_n;       \
+    (void)sp_;
   const unsigned b_row_step = (unsigned)(32 * p.k_pad * 4);
 
   // with no residual the descriptor is empty and every load returns 0
@@ -120,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
       0x00020000);
 
   const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      p.out, 0, (int)((size_t)M * p.cout_store * sizeof(float)), 0x00020000);
+      p.out, 0, (int)((size_t)n_splits * M * p.cout_store * sizeof(float)), 0x00020000);
 
   // tile-queue ticket: a straight-line buffer atomic (only thread 0 has an in-range offset, the range check
   // drops the others) whose result is awaited where it is used, not where it is issued
@@ -147,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
 
 #define UT_SETUP(TILE)                                                                               \
   {                                                                                                  \
-    const int tm_ = (TILE) / tiles_n, tn_ = (TILE) - tm_ * tiles_n;                                  \
+    UT_DECOMP(TILE)                                                                                  \
     _Pragma("unroll") for (int i = 0; i < AP; ++i) {                                                 \
       const int m = tm_ * BM + r0 + 32 * i;                                                          \
       const bool ok = m < M;                                                                         \
@@ -164,6 +179,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     /* C32 (channel slice == chunk width): the thread's 4-float group is folded into a_pix, so (tap, ch,    \
        ch_base) advance identically in every lane and the compiler keeps them - and the tap offset - scalar */ \
     tap = 0; ch = C32 ? 0 : 4 * gk; ch_base = 0;                                                     \
+    if constexpr (SPLITK) {      /* start at chunk sp_ * n_chunks of K */                            \
+      const int k0 = sp_ * n_chunks * BK, per = taps * p.cslice;                                     \
+      const int sl = k0 / per, rem = k0 - sl * per;                                                  \
+      tap = rem / p.cslice;                                                                          \
+      ch += rem - tap * p.cslice;      /* + the thread's own 4-float group when !C32: may cross into the next tap */ \
+      ch_base = sl * p.cslice;                                                                       \
+      if (ch >= p.cslice) { ch -= p.cslice; ++tap; }                                                 \
+      if (tap >= taps) { tap -= taps; ch_base += p.cslice; }                                         \
+      b_off += (unsigned)(k0 * 4);                                                                   \
+    }                                                                                                \
   }
 
   // Prologue only: all AP+BP pieces of a chunk in one burst (the steady state places them one per MFMA step).
@@ -231,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
   // consecutive channels of one pixel: one 16-byte access in NHWC.
 #define UT_INIT_LOAD(TILE)                                                                           \
   {                                                                                                  \
-    const int tm_ = (TILE) / tiles_n, tn_ = (TILE) - tm_ * tiles_n;                                  \
+    UT_DECOMP(TILE)                                                                                  \
     _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                   \
       _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4)                                               \
         bias_raw[j][g4] = *reinterpret_cast<const float4*>(                                          \
@@ -253,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
 #define UT_INIT_LOAD_PART(TILE, Q)                                                                   \
   if constexpr ((Q) < MI * NI) {                                                                     \
     constexpr int i = (Q) / NI, j = (Q) % NI;                                                        \
-    const int tm_ = (TILE) / tiles_n, tn_ = (TILE) - tm_ * tiles_n;                                  \
+    UT_DECOMP(TILE)                                                                                  \
     if constexpr (i == 0) {                                                                          \
       _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4)                                               \
         bias_raw[j][g4] = *reinterpret_cast<const float4*>(                                          \
@@ -314,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     float v[4];                                                                                      \
     _Pragma("unroll") for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[I][J][4 * (G4) + k], e_floor);    \
     if constexpr (!NCHW) {                                                                           \
-      const unsigned off = (m_ok && n < p.cout_store) ? (unsigned)(m * p.cout_store + n) * 4u : OOB; \
+      const unsigned off = (m_ok && n < p.cout_store) ? (unsigned)(m * p.cout_store + n) * 4u + e_slab : OOB; \
       u32x4 pk;                                                                                      \
       pk.x = __float_as_uint(v[0]); pk.y = __float_as_uint(v[1]);                                    \
       pk.z = __float_as_uint(v[2]); pk.w = __float_as_uint(v[3]);                                    \
@@ -433,8 +458,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     // atomic per workgroup per tile, taken a whole tile ahead by wave 0 and handed over through LDS - the chunk
     // barriers in between order it).  Dynamic hand-out keeps every CU busy when the tile count is not a multiple
     // of the resident workgroups; a static stride left up to half of them idle in the last round.
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int e_tm = tm, e_tn = tn;
+    const int e_sp = SPLITK ? tile / real_tiles : 0;
+    const int e_t = tile - e_sp * real_tiles;
+    const int e_tm = e_t / tiles_n, e_tn = e_t - e_tm * tiles_n;
+    const unsigned e_slab = (unsigned)e_sp * (unsigned)(M * p.cout_store) * 4u;     // byte offset of the split's slab
     const float e_floor = p.relu ? 0.f : -__builtin_huge_valf();   // 0 with ReLU, -inf without: one v_max, no branch
     if (n_chunks <= 2) {                  // too few chunk barriers to order the queue slot: do it explicitly
       if (n_chunks == 1 && tid == 0) UT_SLOT_WRITE(grid + ticket);
@@ -456,6 +483,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
   }
 #undef UT_SLOT_WRITE
 #undef UT_SETUP
+#undef UT_DECOMP
 #undef UT_FETCH
 #undef UT_ADVANCE
 #undef UT_INIT_LOAD
@@ -482,18 +510,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
 #undef UT_BARRIER
 }
 
-template <int BM, int BN, int WR, int WC, bool NCHW = false, bool C32 = false>
+template <int BM, int BN, int WR, int WC, bool NCHW = false, bool C32 = false, bool SPLITK = false>
 static hipError_t launch_cfg(const ConvLaunch& c, hipStream_t s) {
   const int M = c.n_img * c.Ho * c.Wo;
   const int tiles_m = (M + BM - 1) / BM;
   const int tiles_n = (c.cout_store + BN - 1) / BN;
-  const int n_tiles = tiles_m * tiles_n;
+  const int n_tiles = tiles_m * tiles_n * (SPLITK ? c.splits : 1);      // queue entries
   const size_t lds = 2 * (size_t)(BM + BN) * LDS_ROW * sizeof(float) + 16;   // + tile-queue slot
   // the attribute belongs to (kernel, device): one bit per device, set on the first launch there
   static std::atomic<unsigned long long> attr_set{0};
   const unsigned long long dev_bit = (c.device >= 0 && c.device < 64) ? 1ull << c.device : 0ull;
   if (!(attr_set.load(std::memory_order_relaxed) & dev_bit) || !dev_bit) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, NCHW, C32>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WR, WC, NCHW, C32, SPLITK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set.fetch_or(dev_bit, std::memory_order_relaxed);
@@ -505,8 +533,36 @@ static hipError_t launch_cfg(const ConvLaunch& c, hipStream_t s) {
   // start stagger of co-resident workgroups: with r of them a chunk takes r x (its MFMA time) of wall time, so the
   // even spacing between ranks is one chunk's MFMA time = (MI*NI) x 16 MFMAs x 64 cycles = (MI*NI) x 2 units
   const int stagger = grid > c.num_cu ? (BM / WR / 32) * (BN / WC / 32) * 2 : 0;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, NCHW, C32>), dim3(grid), dim3(256), lds, s, c, tiles_n, n_tiles,
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WR, WC, NCHW, C32, SPLITK>), dim3(grid), dim3(256), lds, s, c, tiles_n, n_tiles,
                      stagger);
+  return hipGetLastError();
+}
+
+// out = act(bias + residual + slab_0 + slab_1 + ... ) in that order, 4 channels per thread (cout_store % 4 == 0)
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ slabs, int n_splits, int mn4,
+                                                            const float* __restrict__ bias, const float* __restrict__ res,
+                                                            float* __restrict__ out, int cout_store, int relu) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= mn4) return;
+  const int n = (4 * i) % cout_store;
+  float4 v = *reinterpret_cast<const float4*>(bias + n);
+  if (res) {
+    const float4 r = reinterpret_cast<const float4*>(res)[i];
+    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+  }
+  for (int sidx = 0; sidx < n_splits; ++sidx) {
+    const float4 q = reinterpret_cast<const float4*>(slabs)[(size_t)sidx * mn4 + i];
+    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+  }
+  if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  reinterpret_cast<float4*>(out)[i] = v;
+}
+
+hipError_t launch_splitk_finish(const float* slabs, int n_splits, int m, int cout_store, const float* bias,
+                                const float* res, float* out, int relu, hipStream_t s) {
+  const int mn4 = m * cout_store / 4;
+  hipLaunchKernelGGL(splitk_finish_kernel, dim3((mn4 + 255) / 256), dim3(256), 0, s, slabs, n_splits, mn4, bias, res, out,
+                     cout_store, relu);
   return hipGetLastError();
 }
 
@@ -526,11 +582,24 @@ hipError_t launch_conv_igemm(const ConvLaunch& c, hipStream_t s) {
   //  few tiles (the head: 73,728 pixels = 576 tiles of 128 rows on 512 resident slots, i.e. two rounds the
   //  second of which is 12 % full)                                 64x128 tile, three workgroups per CU
   //  backbone, cout > 64 / everything else                         128x128 tile
-  if (conv_patch_applicable(c)) return launch_conv_patch(c, s);
+  //  launches with fewer 64x64 tiles than CUs (a few crops)        64x64 tile
+  if (c.splits > 1) {       // latency mode (ut_api.hip::run_conv): partial sums of K ranges into slabs of c.out
+    if (c.out_nchw || c.res || c.relu || (c.k_pad / BK) % c.splits != 0 ||
+        (size_t)c.splits * c.n_img * c.Ho * c.Wo * c.cout_store * sizeof(float) >= 0x7FFFFF00ull)
+      return hipErrorInvalidValue;
+    return c.cslice == BK ? launch_cfg<64, 64, 2, 2, false, true, true>(c, s) : launch_cfg<64, 64, 2, 2, false, false, true>(c, s);
+  }
+  const long M = (long)c.n_img * c.Ho * c.Wo;
+  const bool few_tiles = ((M + 63) / 64) * ((c.cout_store + 63) / 64) <= (long)c.num_cu;
+  // (latency mode also takes layer1 of a few crops off the halo-patch kernel: 144 small tiles beat 24 large ones)
+  if (conv_patch_applicable(c) && !(c.splits == 1 && few_tiles)) return launch_conv_patch(c, s);
   if (c.out_nchw) return launch_cfg<64, 128, 1, 4, true>(c, s);
   const bool c32 = c.cslice == BK;          // scalar tap bookkeeping
+  // a handful of crops (the per-frame tracker: 4 crops = 576 pixels at 12x12): fewer quarter-size tiles than CUs ->
+  // 64x64 tiles, four times the workgroups and a quarter of the serial K walk per workgroup (same K order per output)
+  if (few_tiles)
+    return c32 ? launch_cfg<64, 64, 2, 2, false, true>(c, s) : launch_cfg<64, 64, 2, 2>(c, s);
   if (c.cout_store <= 64 && c32) return launch_cfg<128, 64, 2, 2, false, true>(c, s);
-  const long M = (long)c.n_img * c.Ho * c.Wo;
   const long tiles128 = ((M + 127) / 128) * ((c.cout_store + 127) / 128);
   if (tiles128 <= 5l * c.num_cu) return launch_cfg<64, 128, 1, 4>(c, s);
   return c32 ? launch_cfg<128, 128, 2, 2, false, true>(c, s) : launch_cfg<128, 128, 2, 2>(c, s);

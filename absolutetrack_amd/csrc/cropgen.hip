@@ -7,7 +7,7 @@
 //   right hands, largest focal that keeps all 63 points in a 96x96 image, times hand_ratio_in_crop
 //                                                                      lib/common/crop.py:15-82, lib/common/affine.py:34-76
 // and the network-side camera inputs of lib/tracker/tracker.py:333-337 (K, world->eye with t in metres).
-// FK in fp32 (the reference runs it in torch fp32), geometry in fp64 (numpy).  One thread per candidate: a few
+// FK in fp32 (the reference runs it in torch fp32), geometry in fp64 (numpy).  One wave per candidate: a few
 // kFLOP and ~1.5 KB each - latency bound; the win over the reference is doing all frames in one launch
 // instead of ~10 ms of numpy/scipy/torch calls per frame.
 #include "ut_fk.h"
@@ -60,9 +60,7 @@ struct CropFit {
 // c2w0: the original camera's camera_to_world (row major 4x4).  Same operation order as the host code
 // (crop.py:57-82, affine.py:47-76): general inverse of camera_to_world, aim +z at `center` in that eye frame,
 // inverse back, right-multiply the rotation by aim and roll, inverse again, mirror, fit the focal length.
-__device__ inline void fit_crop_camera(const double* c2w0, const float* pts, int n_pts, const double* center,
-                                       double angle_deg, bool mirror, int crop_size, double focal_multiplier,
-                                       CropFit& o) {
+__device__ inline void fit_begin(const double* c2w0, const double* center, double angle_deg, bool mirror, double* w2e) {
   double w2e0[16], e2w[16];
   inv4(c2w0, w2e0);
   double c_eye[3];
@@ -90,25 +88,38 @@ __device__ inline void fit_crop_camera(const double* c2w0, const float* pts, int
   mat3_mul(r1, rz, r2);
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) e2w[4 * i + j] = r2[3 * i + j];
-  inv4(e2w, o.w2e);
+  inv4(e2w, w2e);
   if (mirror)                      // diag(-1,1,1,1) @ w2e (crop.py:63-66)
-    for (int j = 0; j < 4; ++j) o.w2e[j] = -o.w2e[j];
-  // intrinsics from the bounding points (crop.py:15-28)
-  double max_ndc = 0.0;
-  bool bad = false;
-  for (int q = 0; q < n_pts; ++q) {
-    const double px = (double)pts[3 * q], py = (double)pts[3 * q + 1], pz = (double)pts[3 * q + 2];
-    const double ex = o.w2e[0] * px + o.w2e[1] * py + o.w2e[2] * pz + o.w2e[3];
-    const double ey = o.w2e[4] * px + o.w2e[5] * py + o.w2e[6] * pz + o.w2e[7];
-    const double ez = o.w2e[8] * px + o.w2e[9] * py + o.w2e[10] * pz + o.w2e[11];
-    if (ez < 0.0001) bad = true;
-    max_ndc = fmax(max_ndc, fmax(fabs(ex / ez), fabs(ey / ez)));
-  }
+    for (int j = 0; j < 4; ++j) w2e[j] = -w2e[j];
+}
+
+// one bounding point through the new world->eye: largest |x/z|, |y/z| so far and the "behind the camera" flag
+// (crop.py:15-28); max is exact, so the points may be visited in any order (or by different lanes)
+__device__ inline void fit_point(const double* w2e, const float* pt, double& max_ndc, bool& bad) {
+  const double px = (double)pt[0], py = (double)pt[1], pz = (double)pt[2];
+  const double ex = w2e[0] * px + w2e[1] * py + w2e[2] * pz + w2e[3];
+  const double ey = w2e[4] * px + w2e[5] * py + w2e[6] * pz + w2e[7];
+  const double ez = w2e[8] * px + w2e[9] * py + w2e[10] * pz + w2e[11];
+  if (ez < 0.0001) bad = true;
+  max_ndc = fmax(max_ndc, fmax(fabs(ex / ez), fabs(ey / ez)));
+}
+
+__device__ inline void fit_end(double max_ndc, bool bad, int crop_size, double focal_multiplier, CropFit& o) {
   o.cxy = ((double)crop_size - 1.0) / 2.0;
   const double fxy = o.cxy / max_ndc;
   o.bad = bad || fxy < 5.0;
   o.focal = focal_multiplier * fxy;
   inv4(o.w2e, o.c2w);              // crop.py:81
+}
+
+__device__ inline void fit_crop_camera(const double* c2w0, const float* pts, int n_pts, const double* center,
+                                       double angle_deg, bool mirror, int crop_size, double focal_multiplier,
+                                       CropFit& o) {
+  fit_begin(c2w0, center, angle_deg, mirror, o.w2e);
+  double max_ndc = 0.0;
+  bool bad = false;
+  for (int q = 0; q < n_pts; ++q) fit_point(o.w2e, pts + 3 * q, max_ndc, bad);
+  fit_end(max_ndc, bad, crop_size, focal_multiplier, o);
 }
 
 // middle of the bounding box, (pts.min + pts.max) / 2.0 (crop.py:60): in fp32 like numpy on float32 points
@@ -129,78 +140,201 @@ __device__ inline void bbox_center(const float* pts, int n_pts, double* center, 
 
 }  // namespace
 
+// One WAVE per candidate (one 64-thread workgroup): the pieces of the per-candidate work that are independent run on
+// different lanes and meet in LDS -
+//   (1) joint transforms of the three crop poses: 3 x 20 lanes            (fk.hip phases 1-3, same arithmetic)
+//   (2) finger chains: 3 x 5 lanes   (3) landmarks: 3 x 21 lanes          -> 63 crop points, fp32
+//   (4) bounding-box centre: 3 lanes (one per axis; min / max are exact)
+//   (5) visible-landmark count: (camera, landmark) pairs on the lanes, three cameras per pass
+//   (6) camera selection: lane 0 (first max_views eligible cameras in index order)
+//   (7) look-at fit: lane v builds view v's new world->eye; the 63 bounding points go one per lane through it
+//       (max / or reductions by wave shuffles: exact in any order); lane v finishes the view and writes its outputs.
+// Every value is computed by the same formula, in the same operation order, as the former one-thread-per-candidate
+// kernel (253 us per launch however few candidates - the per-frame tracker paid that every frame); the results are
+// bit-identical.
+constexpr int CG_MAX_CAMS = 16, CG_MAX_VIEWS = 4;
+
 __global__ __launch_bounds__(64) void cropgen_kernel(CropGenArgs g) {
-  const int s = blockIdx.x * 64 + threadIdx.x;
-  if (s >= g.n) return;
+  const int s = blockIdx.x;
+  const int lane = threadIdx.x;
   const int frame = g.frame_idx[s];
   const int hand = (int)g.hand_idx[s];
   const float* hm = g.hand_model + (size_t)(g.n_models == 1 ? 0 : s) * 321;
+  __shared__ float s_local[3][20][12];
+  __shared__ float s_frame[3][17][12];
+  __shared__ float s_pts[189];
+  __shared__ double s_center[3];
+  __shared__ int s_vis[CG_MAX_CAMS];
+  __shared__ int s_sel[CG_MAX_VIEWS];
+  __shared__ int s_nsel;
+  __shared__ double s_w2e[CG_MAX_VIEWS][16];
 
-  // ---- crop points: FK of the label pose, the neutral pose and the open pose (all with the label wrist)
-  M34 wrist;
-  const float* x = g.wrist_xf + (size_t)s * 16;
-  for (int k = 0; k < 12; ++k) wrist.m[k] = x[k];
-  if (hand == 1) { wrist.m[0] = -wrist.m[0]; wrist.m[4] = -wrist.m[4]; wrist.m[8] = -wrist.m[8]; }
-  float pts[189];
-  float ja[22];
-  for (int k = 0; k < 22; ++k) ja[k] = g.joint_angles[(size_t)s * 22 + k];
-  skin_landmarks_dev(hm, ja, wrist, pts);
-  if (g.landmarks)      // the label pose's landmarks = landmarks_from_hand_pose(hand_model, pose, hand_idx), same FK as ut_fk
-    for (int k = 0; k < 63; ++k) g.landmarks[(size_t)s * 63 + k] = pts[k];
-  const float* lim = g.joint_limits + (size_t)(g.n_models == 1 ? 0 : s) * 44;
-  for (int k = 0; k < 22; ++k) ja[k] = lim[2 * k] * 0.5f + lim[2 * k + 1] * (1.0f - 0.5f);   // perspective_crop.py:19-24
-  skin_landmarks_dev(hm, ja, wrist, pts + 63);
-  for (int k = 0; k < 22; ++k) ja[k] = 0.f;
-  skin_landmarks_dev(hm, ja, wrist, pts + 126);
-
-  double center[3];
-  bbox_center(pts, 63, center);
-
-  int n_views = 0, status = 0;
-  for (int ci = 0; ci < g.n_cams && n_views < g.max_views; ++ci) {
-    const double* cam = g.cam_params + ((size_t)frame * g.n_cams + ci) * 32;
-    // visibility count of the label-pose landmarks
-    int vis = 0;
-    for (int l = 0; l < 21; ++l) {
-      const double w[3] = {(double)pts[3 * l], (double)pts[3 * l + 1], (double)pts[3 * l + 2]};
+  // ---- (1) joint local transforms of the label pose, the neutral pose and the open pose; wrist frames
+  if (lane < 60) {
+    const int pz = lane / 20, q = lane - pz * 20;
+    float angle;
+    if (pz == 0) angle = g.joint_angles[(size_t)s * 22 + q];
+    else if (pz == 1) {                                   // perspective_crop.py:19-24
+      const float* lim = g.joint_limits + (size_t)(g.n_models == 1 ? 0 : s) * 44;
+      angle = lim[2 * q] * 0.5f + lim[2 * q + 1] * (1.0f - 0.5f);
+    } else angle = 0.f;
+    const M34 l = joint_local(hm + 3 * q, hm + 66 + 3 * q, angle);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) s_local[pz][q][k] = l.m[k];
+  } else if (lane < 63) {
+    const int pz = lane - 60;
+    const float* x = g.wrist_xf + (size_t)s * 16;
+    M34 w;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) w.m[k] = x[k];
+    if (hand == 1) { w.m[0] = -w.m[0]; w.m[4] = -w.m[4]; w.m[8] = -w.m[8]; }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { s_frame[pz][0][k] = w.m[k]; s_frame[pz][1][k] = w.m[k]; }
+  }
+  if (lane < CG_MAX_CAMS) s_vis[lane] = 0;
+  __syncthreads();
+  // ---- (2) finger chains
+  if (lane < 15) {
+    const int pz = lane / 5, f = lane - pz * 5;
+    M34 t;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) t.m[k] = s_frame[pz][0][k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      M34 l;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) l.m[k] = s_local[pz][4 * f + j][k];
+      t = mul34(t, l);
+      if (j >= 1) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) s_frame[pz][2 + 3 * f + (j - 1)][k] = t.m[k];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- (3) linear blend skinning, frames visited in ascending order like the dense reference sum
+  if (lane < 63) {
+    const int pz = lane / 21, l = lane - pz * 21;
+    const float* lm = hm + 132;
+    const float* wts = hm + 195;
+    const float* idx = hm + 258;
+    const float px = lm[3 * l], py = lm[3 * l + 1], pzz = lm[3 * l + 2];
+    const float w0 = wts[3 * l], w1 = wts[3 * l + 1], w2 = wts[3 * l + 2];
+    const int i0 = (int)idx[3 * l], i1 = (int)idx[3 * l + 1], i2 = (int)idx[3 * l + 2];
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int f = 0; f < 17; ++f) {
+      float w = 0.f;
+      if (w0 != 0.f && i0 == f) w = w0;
+      if (w1 != 0.f && i1 == f) w = w1;
+      if (w2 != 0.f && i2 == f) w = w2;
+      if (w != 0.f) {
+        const float* t = s_frame[pz][f];
+        const float qx = px * w, qy = py * w, qz = pzz * w;
+        ax += t[0] * qx + t[1] * qy + t[2] * qz + t[3] * w;
+        ay += t[4] * qx + t[5] * qy + t[6] * qz + t[7] * w;
+        az += t[8] * qx + t[9] * qy + t[10] * qz + t[11] * w;
+      }
+    }
+    s_pts[3 * lane] = ax; s_pts[3 * lane + 1] = ay; s_pts[3 * lane + 2] = az;
+    if (pz == 0 && g.landmarks) {   // = landmarks_from_hand_pose(hand_model, pose, hand_idx), same FK as ut_fk
+      float* o = g.landmarks + (size_t)s * 63 + 3 * l;
+      o[0] = ax; o[1] = ay; o[2] = az;
+    }
+  }
+  __syncthreads();
+  // ---- (4) middle of the bounding box in fp32 like (pts.min + pts.max) / 2.0 on float32 points (crop.py:60)
+  if (lane < 3) {
+    float lo = 3.0e38f, hi = -3.0e38f;
+    for (int q = 0; q < 63; ++q) {
+      lo = fminf(lo, s_pts[3 * q + lane]);
+      hi = fmaxf(hi, s_pts[3 * q + lane]);
+    }
+    s_center[lane] = (double)((lo + hi) / 2.0f);
+  }
+  // ---- (5) visibility of the label-pose landmarks in every camera
+  for (int c0 = 0; c0 < g.n_cams; c0 += 3) {
+    const int ci = c0 + lane / 21, l = lane % 21;
+    if (lane < 63 && ci < g.n_cams) {
+      const double* cam = g.cam_params + ((size_t)frame * g.n_cams + ci) * 32;
+      const double w[3] = {(double)s_pts[3 * l], (double)s_pts[3 * l + 1], (double)s_pts[3 * l + 2]};
       double e[3], win[2];
       world_to_eye_d(cam, w, e);
       fisheye_project_d(cam, e, win);
-      vis += (win[0] >= 0 && win[0] <= g.src_w - 1 && win[1] >= 0 && win[1] <= g.src_h - 1 && e[2] > 0) ? 1 : 0;
+      if (win[0] >= 0 && win[0] <= g.src_w - 1 && win[1] >= 0 && win[1] <= g.src_h - 1 && e[2] > 0) atomicAdd(&s_vis[ci], 1);
     }
-    if (vis < g.min_vis) continue;
-
+  }
+  __syncthreads();
+  // ---- (6) the first max_views eligible cameras in index order (sort_camera_index=True)
+  if (lane == 0) {
+    int n = 0;
+    for (int ci = 0; ci < g.n_cams && n < g.max_views; ++ci)
+      if (s_vis[ci] >= g.min_vis) s_sel[n++] = ci;
+    s_nsel = n;
+  }
+  __syncthreads();
+  const int n_views = s_nsel;
+  // ---- (7) look-at fit per selected view
+  if (lane < n_views) {
+    const int ci = s_sel[lane];
+    const double* cam = g.cam_params + ((size_t)frame * g.n_cams + ci) * 32;
     const double* rc = cam + 12;     // camera_to_world rotation (row major), translation at cam+21
     const double* tc = cam + 21;
     const double c2w0[16] = {rc[0], rc[1], rc[2], tc[0], rc[3], rc[4], rc[5], tc[1], rc[6], rc[7], rc[8], tc[2], 0, 0, 0, 1};
+    const double center[3] = {s_center[0], s_center[1], s_center[2]};
+    double w2e[16];
+    fit_begin(c2w0, center, g.camera_angles[ci], hand == 1, w2e);
+    for (int k = 0; k < 16; ++k) s_w2e[lane][k] = w2e[k];
+  }
+  __syncthreads();
+  double my_ndc = 0.0;      // of the view this lane will finish (lane v < n_views)
+  bool my_bad = false;
+  for (int v = 0; v < n_views; ++v) {
+    double m = 0.0;
+    bool bad = false;
+    if (lane < 63) fit_point(s_w2e[v], s_pts + 3 * lane, m, bad);
+    int badi = bad ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      m = fmax(m, __shfl_xor(m, off));
+      badi |= __shfl_xor(badi, off);
+    }
+    if (lane == v) { my_ndc = m; my_bad = badi != 0; }
+  }
+  int my_status = 0;
+  if (lane < n_views) {
     CropFit fit;
-    fit_crop_camera(c2w0, pts, 63, center, g.camera_angles[ci], hand == 1, g.crop_size, g.focal_multiplier, fit);
-    if (fit.bad) status = 1;
+    for (int k = 0; k < 16; ++k) fit.w2e[k] = s_w2e[lane][k];
+    fit_end(my_ndc, my_bad, g.crop_size, g.focal_multiplier, fit);
+    if (fit.bad) my_status = 1;
     const double focal = fit.focal, cxy = fit.cxy;
     const double* c2w = fit.c2w;
-
     // ---- outputs
-    double* cp = g.crop_params + ((size_t)s * g.max_views + n_views) * 24;
+    double* cp = g.crop_params + ((size_t)s * g.max_views + lane) * 24;
     cp[0] = focal; cp[1] = focal; cp[2] = cxy; cp[3] = cxy;
     for (int i = 0; i < 3; ++i) {
       for (int j = 0; j < 3; ++j) cp[4 + 3 * i + j] = c2w[4 * i + j];
       cp[13 + i] = c2w[4 * i + 3];
     }
     for (int i = 16; i < 24; ++i) cp[i] = 0.0;
-    float* kk = g.intrinsics + ((size_t)s * g.max_views + n_views) * 9;
+    float* kk = g.intrinsics + ((size_t)s * g.max_views + lane) * 9;
     kk[0] = (float)focal; kk[1] = 0.f; kk[2] = (float)cxy; kk[3] = 0.f; kk[4] = (float)focal; kk[5] = (float)cxy;
     kk[6] = 0.f; kk[7] = 0.f; kk[8] = 1.f;
     // extrinsics = inv(crop camera_to_world) with the translation in metres (tracker.py:335-337)
     double ext[16];
     inv4(c2w, ext);
-    float* ex = g.extrinsics + ((size_t)s * g.max_views + n_views) * 16;
+    float* ex = g.extrinsics + ((size_t)s * g.max_views + lane) * 16;
     for (int i = 0; i < 16; ++i) ex[i] = (float)((i % 4 == 3 && i < 12) ? ext[i] * 0.001 : ext[i]);
-    g.cam_index[(size_t)s * g.max_views + n_views] = ci;
-    ++n_views;
+    g.cam_index[(size_t)s * g.max_views + lane] = s_sel[lane];
+  } else if (lane < g.max_views) {
+    g.cam_index[(size_t)s * g.max_views + lane] = -1;
   }
-  for (int vdx = n_views; vdx < g.max_views; ++vdx) g.cam_index[(size_t)s * g.max_views + vdx] = -1;
-  g.n_views[s] = n_views;
-  g.status[s] = status;
+  // "Unable to create crop camera" on any selected view
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) my_status |= __shfl_xor(my_status, off);
+  if (lane == 0) {
+    g.n_views[s] = n_views;
+    g.status[s] = my_status;
+  }
 }
 
 // torch_data path: _gen_crop_matrices of lib/batched_dataset/data_transform.py:147-212
@@ -256,7 +390,8 @@ hipError_t launch_cropmat(const CropMatArgs& g, hipStream_t s) {
 
 hipError_t launch_cropgen(const CropGenArgs& g, hipStream_t s) {
   if (g.n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(cropgen_kernel, dim3((g.n + 63) / 64), dim3(64), 0, s, g);
+  if (g.n_cams > CG_MAX_CAMS || g.max_views > CG_MAX_VIEWS) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(cropgen_kernel, dim3(g.n), dim3(64), 0, s, g);
   return hipGetLastError();
 }
 

@@ -86,6 +86,11 @@ struct ut_context {
   int* status_host = nullptr;
   int* slot_seen = nullptr;
   int check_mode = UT_CHECK_SYNC;
+  // latency mode (ut_set_latency_mode): launches with far fewer tiles than CUs split K across workgroups
+  bool latency_mode = false;
+  float* splitk_ws = nullptr;      // [splits][M][cout] partial sums
+  size_t splitk_floats = 0;
+  float* zero_bias = nullptr;      // 256 zeros
   // profiling
   bool profiling = false;
   std::vector<ProfEvent> prof;
@@ -392,6 +397,28 @@ int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, fl
     if (rc0) return rc0;
   }
   c.tile_counter = h->counters + h->counter_next++;
+  // Latency mode: a convolution of a few crops has far fewer 64x64 tiles than the chip has CUs and every workgroup
+  // walks all of K alone (a layer-4 conv of 4 crops: 12 tiles x 72 chunks).  Cut K into S equal chunk ranges (S the
+  // largest divisor of the chunk count that leaves >= 6 chunks per range and <= one workgroup per CU), let S x tiles
+  // workgroups write partial sums and add them in a fixed order afterwards.  Deterministic, but the summation order
+  // differs from the unsplit kernel's: results agree with it to fp32 rounding, not bit for bit - hence opt-in.
+  int splits = 1;
+  if (h->latency_mode && !nchw && cw.cout_store % 4 == 0) {
+    const long m = (long)n_img * c.Ho * c.Wo;
+    const long tiles64 = ((m + 63) / 64) * ((cw.cout_store + 63) / 64);
+    const int chunks = cw.k_pad / 32;
+    for (int sp = 2; sp <= chunks / 6; ++sp)
+      if (chunks % sp == 0 && tiles64 * sp <= (long)h->num_cu && (size_t)sp * m * cw.cout_store <= h->splitk_floats) splits = sp;
+  }
+  if (h->latency_mode) c.splits = 1;
+  if (splits > 1) {
+    ut::ConvLaunch part = c;
+    part.bias = h->zero_bias; part.res = nullptr; part.relu = 0; part.out = h->splitk_ws; part.splits = splits;
+    HIPCHK(h, ut::launch_conv_igemm(part, s));
+    HIPCHK(h, ut::launch_splitk_finish(h->splitk_ws, splits, n_img * c.Ho * c.Wo, cw.cout_store, cw.bias, res, out,
+                                       relu ? 1 : 0, s));
+    return UT_OK;
+  }
   ProfEvent pe{};
   if (h->profiling) {
     HIPCHK(h, hipEventCreateWithFlags(&pe.a, hipEventDisableSystemFence));   // timing only: no system-scope flush per kernel
@@ -839,6 +866,20 @@ int ut_keypoint_metrics(ut_handle h, const float* gt, const float* tracked, cons
   ON_DEVICE_IF(h);
   HIPCHK(h, ut::launch_keypoint_metrics(gt, tracked, valid, n_hands, n_frames, err, acc, gt_acc, valid_acc,
                                         (hipStream_t)stream));
+  return UT_OK;
+}
+
+int ut_set_latency_mode(ut_handle h, int on) {
+  if (!h) return UT_E_INVALID;
+  ON_DEVICE_OF(h);
+  if (on && !h->splitk_ws) {
+    const size_t n = 1u << 20;          // 4 MB: S x M x cout of every few-crop layer of this network is 442 k floats
+    int rc;
+    if ((rc = dev_alloc(h, &h->splitk_ws, n)) || (rc = dev_alloc(h, &h->zero_bias, 256))) return rc;
+    HIPCHK(h, hipMemset(h->zero_bias, 0, 256 * sizeof(float)));
+    h->splitk_floats = n;
+  }
+  h->latency_mode = on != 0;
   return UT_OK;
 }
 

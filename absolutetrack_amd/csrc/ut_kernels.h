@@ -30,9 +30,14 @@ struct ConvLaunch {
   int device;          // HIP device the launch goes to (the dynamic-LDS attribute is set once per device)
   int num_cu;          // compute units of the device (persistent grid sizing)
   unsigned* tile_counter;   // device word, zero before the launch: dynamic tile queue of the persistent grid
+  int splits;          // > 1 (latency mode): K is cut in `splits` equal chunk ranges, out = [splits][M][cout_store] slabs;
+                       // 1 = latency mode without a split (prefers small tiles); 0 = throughput dispatch
 };
 
 hipError_t launch_conv_igemm(const ConvLaunch& c, hipStream_t s);
+// latency mode: out = act(bias + res + sum of the split-K slabs, in slab order)
+hipError_t launch_splitk_finish(const float* slabs, int n_splits, int m, int cout_store, const float* bias,
+                                const float* res, float* out, int relu, hipStream_t s);
 // 3x3 stride-1 32->32 channel convs with the halo patch resident in LDS (conv_patch.hip)
 bool conv_patch_applicable(const ConvLaunch& c);
 hipError_t launch_conv_patch(const ConvLaunch& c, hipStream_t s);

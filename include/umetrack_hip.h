@@ -75,6 +75,12 @@ int ut_set_index_checks(ut_handle h, int mode);
  * call on this handle since the last poll, else UT_OK. */
 int ut_poll_status(ut_handle h, void* stream);
 
+/* Latency mode for calls on a handful of crops (the per-frame tracker): convolutions whose launch has far fewer tiles
+ * than the chip has CUs split K across workgroups and add the partial sums in a fixed order.  Deterministic, but not
+ * the unsplit kernel's summation order: results agree with the default mode to fp32 rounding (~1e-6 relative), not
+ * bit for bit, which is why it is opt-in (0 = off, the default).  Large batches are unaffected. */
+int ut_set_latency_mode(ut_handle h, int on);
+
 /* Pre-size the activation workspace / temporal state so that later calls never allocate
  * (needed before capturing calls into a hipGraph). */
 int ut_reserve(ut_handle h, int max_crops, int max_samples, int max_slots);

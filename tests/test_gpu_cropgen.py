@@ -148,6 +148,21 @@ def test_no_eligible_view_and_unbuildable_crop(labels, hand_model):
                                    min_required_vis_landmarks=0)
 
 
+def test_landmarks_output_equals_fk(labels, hand_model):
+    """The optional landmarks output (the label pose's first 21 crop points) is ut_fk of the same pose, bit for bit -
+    what the per-frame tracker hands to landmarks_from_hand_pose instead of a second launch."""
+    c = pipeline.label_candidates(labels, list(range(0, 369, 7)))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    blob = torch.from_numpy(_native.hand_model_blob(
+        hand_model.joint_rotation_axes, hand_model.joint_rest_positions, hand_model.landmark_rest_positions,
+        hand_model.landmark_rest_bone_weights, hand_model.landmark_rest_bone_indices)).reshape(1, 321).to(DEV)
+    g = _native.gen_crop_cameras(t(c["cam_params"]), t(c["camera_angles"]), blob, hand_model.joint_limits.float().to(DEV),
+                                 t(c["joint_angles"]), t(c["wrist_xf"]), t(c["frame_idx"]), t(c["hand_idx"]), c["n_cams"],
+                                 c["src_wh"], want_landmarks=True)
+    want = _native.fk_stateless(blob, t(c["joint_angles"]), t(c["wrist_xf"]), mirror=t(c["hand_idx"]))
+    assert g["landmarks"].shape == want.shape and torch.equal(g["landmarks"], want)
+
+
 def test_argument_checks(labels, hand_model):
     c = pipeline.label_candidates(labels, [0])
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
@@ -166,7 +181,7 @@ def test_argument_checks(labels, hand_model):
                                  c["src_wh"])
     lib = _native.load_library()
     assert lib.ut_gen_crop_cameras(None, None, None, None, None, 1, None, None, None, None, 4, 4, 2, 19, 636, 480, 96,
-                                   0.8, None, None, None, None, None, None, None) != 0
+                                   0.8, None, None, None, None, None, None, None, None) != 0
     assert b"ut_gen_crop_cameras" in lib.ut_last_error(None)
 
 

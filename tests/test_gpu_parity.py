@@ -322,6 +322,31 @@ def test_fused_resample_backbone_equals_the_two_calls(engine, mode):
         engine.warp_backbone(src, cam, crop, _dev(np.array([0, 1, 2, 3, 4, 5, 6, 8], np.int32)), mode)
 
 
+def test_latency_mode_matches_the_default_to_rounding(engine):
+    """ut_set_latency_mode: convolutions of a few crops split K across workgroups and add the slabs in a fixed order
+    (csrc/ut_api.hip::run_conv).  Same sums in another order: the features agree with the default mode to fp32
+    rounding, run to run identically; launches with enough tiles (a batch) are not split and stay bit-identical."""
+    fast = _native.HipEngine(synth.synthetic_state_dict(0), DEV)
+    try:
+        fast.set_latency_mode(True)
+        for n in (1, 4):
+            crops = _dev(synth.synthetic_crops(n, seed=20 + n))
+            want = engine.backbone(crops)
+            got = fast.backbone(crops)
+            scale = float(want.abs().max())
+            assert float((got - want).abs().max()) < 2e-5 * max(scale, 1.0), (n, float((got - want).abs().max()), scale)
+            assert torch.equal(fast.backbone(crops), got)                 # deterministic
+        d = _head_inputs(engine, n_samples=2, seed=5)
+        engine.reset_memory()
+        fast.reset_memory()
+        p0, p1 = _head_call(engine, d, n_slots=2), _head_call(fast, d, n_slots=2)
+        assert float((p0 - p1).abs().max()) < 1e-5
+        big = _dev(synth.synthetic_crops(300, seed=9))
+        assert torch.equal(fast.backbone(big), engine.backbone(big))      # enough tiles: no split
+    finally:
+        fast.close()
+
+
 def _head_inputs(engine, n_samples=3, seed=2):
     n = 2 * n_samples
     g = torch.Generator(device=DEV)

@@ -92,6 +92,50 @@ def test_reference_script_flow_matches_oracle(labels, hand_model):
     assert not trk._valid_tracking_history.any()
 
 
+def test_staged_per_frame_path_equals_the_general_path(labels, hand_model):
+    """HandTracker.track_frame normally runs staged (one upload of images + parameter rows, the fused resample+backbone
+    entry, FK of the regressed poses in the same launch sequence, one read-back, landmarks remembered for
+    landmarks_from_hand_pose).  It must return exactly what the general tensor-by-tensor path returns, frame after
+    frame with the temporal memory engaged, and the remembered landmarks must be exactly the FK of the returned pose."""
+    from lib.models.umetrack_model import UmeTrackModel
+    from lib.tracker.perspective_crop import landmarks_from_hand_pose
+    from lib.tracker.tracker import HandTracker, HandTrackerOpts
+    from absolutetrack_amd import tracker as tk
+    sd = synth.synthetic_state_dict(0)
+    fast = HandTracker(UmeTrackModel(sd), HandTrackerOpts())
+    slow = HandTracker(UmeTrackModel(sd), HandTrackerOpts())
+    slow._run_staged = lambda *a, **k: None            # force the general path
+    frames = synth.synthetic_frames(4, seed=13)
+    for step, fi in enumerate((100, 101, 102, 103)):
+        sample, cams = _input_frame(labels, fi, frames[step])
+        gt = _gt(labels, fi)
+        if step == 2:
+            gt = {1: gt[1]}                             # one hand only: other shapes, a slot drops out
+        cc = fast.gen_crop_cameras(cams, list(labels["camera_angles"]), hand_model, gt, min_num_crops=1)
+        a = fast.track_frame(sample, hand_model, cc)
+        b = slow.track_frame(sample, hand_model, cc)
+        assert sorted(a.hand_poses) == sorted(b.hand_poses) == sorted(gt) and a.num_views == b.num_views
+        for h in a.hand_poses:
+            assert np.array_equal(a.hand_poses[h].joint_angles, b.hand_poses[h].joint_angles)
+            assert np.array_equal(a.hand_poses[h].wrist_xform, b.hand_poses[h].wrist_xform)
+            tk._landmark_memo.items.clear()
+            direct = landmarks_from_hand_pose(hand_model, b.hand_poses[h], h)       # FK launch
+        assert (fast._valid_tracking_history == slow._valid_tracking_history).all()
+    # remembered landmarks: track_frame's and gen_crop_cameras' (label poses) are the FK results, bit for bit
+    sample, cams = _input_frame(labels, 104, frames[0])
+    gt = _gt(labels, 104)
+    cc = fast.gen_crop_cameras(cams, list(labels["camera_angles"]), hand_model, gt, min_num_crops=1)
+    res = fast.track_frame(sample, hand_model, cc)
+    for h in (0, 1):
+        for pose in (res.hand_poses[h], gt[h]):
+            assert tk._landmark_memo.get(hand_model, h, pose.joint_angles, pose.wrist_xform) is not None
+            remembered = landmarks_from_hand_pose(hand_model, pose, h)
+            keep = list(tk._landmark_memo.items)
+            tk._landmark_memo.items.clear()
+            assert np.array_equal(remembered, landmarks_from_hand_pose(hand_model, pose, h))
+            tk._landmark_memo.items[:] = keep
+
+
 def test_calibration_path_matches_oracle(labels, hand_model):
     from lib.models.umetrack_model import UmeTrackModel
     from lib.tracker.tracker import HandTracker, HandTrackerOpts

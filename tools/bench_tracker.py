@@ -14,6 +14,8 @@ from absolutetrack_amd import pipeline, synth  # noqa: E402
 
 
 def main():
+    import faulthandler
+    faulthandler.dump_traceback_later(300, exit=True)      # a hung launch sequence shows where, then exits
     n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 200
     from lib.models.umetrack_model import UmeTrackModel
     from lib.tracker.perspective_crop import landmarks_from_hand_pose
