@@ -234,6 +234,44 @@ def test_full_size_batch_invariances(engine):
     assert (pose[:, 20:22] == 0).all() and (pose[:, 39:60] >= 1e-5).all()
 
 
+def test_c5_per_rank_workload_properties():
+    """BASELINE config C5 per rank (1024 frames x 4 cameras x 2 hands = 2048 hand-frames, 4096 crops - what one rank of
+    the 8-GPU run processes per step, and bench.py's step): the fused path's records must be finite, must not depend
+    on how the frames are cut into batches (each half run alone gives the same records, bit for bit: frames are
+    independent, `memory_idx = arange`), the keypoints in a record must be the FK of that record's pose, wrist
+    transforms rigid, and the unfused path (fp32 crops materialised) must give the same records."""
+    lab = pipeline.load_labels()
+    hm = pipeline.hand_model_from_labels(lab)
+    eng = _native.HipEngine(synth.synthetic_state_dict(0), DEV)
+    try:
+        f = 1024
+        g = torch.Generator(device=DEV)
+        g.manual_seed(99)
+        src = torch.randint(0, 256, (f * 4, 480, 636), dtype=torch.uint8, device=DEV, generator=g)
+        plan = {k: v.cpu().numpy() for k, v in pipeline.crop_plan_on_device(lab, hm, range(f), DEV).items()}
+        hot = pipeline.HotPath(eng, hm)
+        rec = hot.step(pipeline.make_batch(plan, src, DEV)).clone()
+        hot.check()
+        assert rec.shape == (2048, pipeline.RECORD) and torch.isfinite(rec).all()
+        for lo, hi in ((0, 512), (512, 1024)):
+            sub = {k: v.cpu().numpy() for k, v in pipeline.crop_plan_on_device(lab, hm, range(lo, hi), DEV).items()}
+            part = pipeline.HotPath(eng, hm).step(pipeline.make_batch(sub, src[lo * 4: hi * 4], DEV))
+            assert torch.equal(part, rec[2 * lo: 2 * hi]), (lo, hi)
+        unfused = pipeline.HotPath(eng, hm, keep_crops=True).step(pipeline.make_batch(plan, src, DEV))
+        assert torch.equal(unfused, rec)
+        blob = torch.from_numpy(_native.hand_model_blob(hm.joint_rotation_axes, hm.joint_rest_positions,
+                                                        hm.landmark_rest_positions, hm.landmark_rest_bone_weights,
+                                                        hm.landmark_rest_bone_indices)).reshape(1, 321).to(DEV)
+        hand = torch.from_numpy(plan["hand_idx"]).to(DEV)
+        kp = eng.fk(blob, rec[:, :22].contiguous(), rec[:, 22:38].reshape(-1, 4, 4).contiguous(), mirror=hand, t_scale=1000.0)
+        assert torch.equal(kp.reshape(2048, -1), rec[:, 60:])
+        r = rec[:, 22:38].reshape(-1, 4, 4)[:, :3, :3].double()
+        assert (r @ r.transpose(1, 2) - torch.eye(3, device=DEV, dtype=torch.float64)).abs().max() < 1e-5
+        assert torch.allclose(torch.linalg.det(r), torch.where(hand == 1, -1.0, 1.0).double(), atol=1e-5)
+    finally:
+        eng.close()
+
+
 def test_fk_rigid_equivariance_full_size(engine):
     """FK(T * wrist) == T * FK(wrist) for a rigid T, on 8192 x 2 poses (BASELINE config C5 record count)."""
     lab = pipeline.load_labels()

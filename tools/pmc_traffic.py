@@ -3,7 +3,10 @@
 a pass on gfx950: MI355X_MICROARCH.md "rocprofv3 PMC slots").  Corrections per that guide's HBM section:
 counters are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a wide (16 B/lane) coalesced read, so it is
 doubled; WRITE_SIZE is exact for 16 B/lane stores.
-    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [label]"""
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [label] [n_steps]
+With n_steps (hot-path steps the profiled command ran, warm-up included) the summary also holds the HBM bytes of one
+whole step over ALL of the library's kernels (resampler, stem, convolutions, head glue, FK) and their ratio to the
+algorithmic bytes of SURVEY.md 8(d) (2048 hand-frames x 74,220 B)."""
 import csv
 import json
 import sys
@@ -18,6 +21,16 @@ def per_launch(path, counter):
     return tot, n
 
 
+def per_kernel(path, counter):
+    tot = {}
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"]
+        if r["Counter_Name"] == counter and ("ut::" in k):
+            name = k.split("(")[0].replace("void ", "")
+            tot[name] = tot.get(name, 0.0) + float(r["Counter_Value"])
+    return tot
+
+
 fetch, nf = per_launch(sys.argv[1], "FETCH_SIZE")
 write, nw = per_launch(sys.argv[2], "WRITE_SIZE")
 out = {
@@ -27,5 +40,14 @@ out = {
     "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE counts 64 B per 128-B request)",
     "traffic_bytes_per_launch": (2.0 * fetch / max(nf, 1) + write / max(nw, 1)) * 1024.0,
 }
+if len(sys.argv) > 5:
+    n_steps = int(sys.argv[5])
+    fk, wk = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+    per = {k: (2.0 * fk.get(k, 0.0) + wk.get(k, 0.0)) * 1024.0 / n_steps for k in sorted(set(fk) | set(wk))}
+    step = sum(per.values())
+    algo = 2048 * 74220.0
+    out.update({"steps_in_run": n_steps, "step_traffic_bytes_all_kernels": step,
+                "step_traffic_bytes_by_kernel": {k: round(v) for k, v in sorted(per.items(), key=lambda kv: -kv[1])},
+                "algorithmic_bytes_per_step": algo, "ratio_to_algorithmic": step / algo})
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))

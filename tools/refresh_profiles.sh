@@ -17,6 +17,6 @@ cp /tmp/prof_s/run_kernel_stats.csv $O/bench_kernel_stats.csv
 python3 $R/tools/layer_profile.py /tmp/prof_s/run_kernel_trace.csv 4096 4096 > $O/bench_conv_layers.txt 2>&1 || exit 1
 rm -rf /tmp/prof_f && timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_f -o run --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-roofline --parity-frames 0 --cpu-frames 0 > /dev/null 2>&1 || exit 1
 rm -rf /tmp/prof_w && timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE -d /tmp/prof_w -o run --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-roofline --parity-frames 0 --cpu-frames 0 > /dev/null 2>&1 || exit 1
-python3 $R/tools/pmc_traffic.py /tmp/prof_f/run_counter_collection.csv /tmp/prof_w/run_counter_collection.csv $O/conv_traffic.json "bench.py --steps 2 --warmup 1, 4096 crops / 2048 hand-frames per step" || exit 1
+python3 $R/tools/pmc_traffic.py /tmp/prof_f/run_counter_collection.csv /tmp/prof_w/run_counter_collection.csv $O/conv_traffic.json "bench.py --steps 2 --warmup 1, 4096 crops / 2048 hand-frames per step" 3 || exit 1
 tail -3 $O/bench_conv_layers.txt
 cat $O/bench_line.json
