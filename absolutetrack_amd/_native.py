@@ -22,6 +22,7 @@ EXPORTS = (
     "ut_reset_memory", "ut_get_memory", "ut_fk", "ut_gen_crop_cameras", "ut_gen_crop_matrices",
     "ut_resample_homography", "ut_keypoint_metrics", "ut_profile_begin", "ut_profile_end",
     "ut_set_index_checks", "ut_poll_status", "ut_warp_backbone", "ut_set_latency_mode",
+    "ut_set_backbone_lanes",
 )
 
 UT_MODE_KNOWN, UT_MODE_UNKNOWN = 0, 1
@@ -90,6 +91,8 @@ def load_library() -> ctypes.CDLL:
                                    ctypes.POINTER(ctypes.c_double)]
     lib.ut_set_index_checks.restype = i32
     lib.ut_set_index_checks.argtypes = [vp, i32]
+    lib.ut_set_backbone_lanes.restype = i32
+    lib.ut_set_backbone_lanes.argtypes = [vp, i32]
     lib.ut_set_latency_mode.restype = i32
     lib.ut_set_latency_mode.argtypes = [vp, i32]
     lib.ut_poll_status.restype = i32
@@ -355,6 +358,10 @@ class HipEngine:
         the device and `poll_status()` raises for it later."""
         self._check(self.lib.ut_set_index_checks(self._h, UT_CHECK_DEFERRED if deferred else UT_CHECK_SYNC),
                     "ut_set_index_checks")
+
+    def set_backbone_lanes(self, lanes: int):
+        """2: large batches run as two half-batches on two internal streams (each fills the other's launch tails)."""
+        self._check(self.lib.ut_set_backbone_lanes(self._h, int(lanes)), "ut_set_backbone_lanes")
 
     def set_latency_mode(self, on: bool):
         """Few-crop launches split K across workgroups (per-frame tracking); results then agree with the default mode to

@@ -580,7 +580,7 @@ hipError_t launch_conv_igemm(const ConvLaunch& c, hipStream_t s) {
   //  projection (the only NCHW output)                             64x128 tile
   //  backbone, cout <= 64  (channel slice == chunk width)          128x64 tile, three workgroups per CU
   //  few tiles (the head: 73,728 pixels = 576 tiles of 128 rows on 512 resident slots, i.e. two rounds the
-  //  second of which is 12 % full)                                 64x128 tile, three workgroups per CU
+  //  second of which is 12 % full; up to 3 x 256 full-height tiles)  64x128 tile, three workgroups per CU
   //  backbone, cout > 64 / everything else                         128x128 tile
   //  launches with fewer 64x64 tiles than CUs (a few crops)        64x64 tile
   if (c.splits > 1) {       // latency mode (ut_api.hip::run_conv): partial sums of K ranges into slabs of c.out
@@ -601,7 +601,7 @@ hipError_t launch_conv_igemm(const ConvLaunch& c, hipStream_t s) {
     return c32 ? launch_cfg<64, 64, 2, 2, false, true>(c, s) : launch_cfg<64, 64, 2, 2>(c, s);
   if (c.cout_store <= 64 && c32) return launch_cfg<128, 64, 2, 2, false, true>(c, s);
   const long tiles128 = ((M + 127) / 128) * ((c.cout_store + 127) / 128);
-  if (tiles128 <= 5l * c.num_cu) return launch_cfg<64, 128, 1, 4>(c, s);
+  if (tiles128 <= 3l * c.num_cu) return launch_cfg<64, 128, 1, 4>(c, s);
   return c32 ? launch_cfg<128, 128, 2, 2, false, true>(c, s) : launch_cfg<128, 128, 2, 2>(c, s);
 }
 

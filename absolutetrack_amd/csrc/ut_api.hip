@@ -86,6 +86,11 @@ struct ut_context {
   int* status_host = nullptr;
   int* slot_seen = nullptr;
   int check_mode = UT_CHECK_SYNC;
+  // backbone lanes (ut_set_backbone_lanes): a large batch runs as two half-batches on two internal streams, so that
+  // the tail of one lane's launch (workgroups that found the tile queue empty) is filled by the other lane's launch
+  int lanes = 1;
+  hipStream_t lane_stream[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   // latency mode (ut_set_latency_mode): launches with far fewer tiles than CUs split K across workgroups
   bool latency_mode = false;
   float* splitk_ws = nullptr;      // [splits][M][cout] partial sums
@@ -545,6 +550,11 @@ int ut_destroy(ut_handle h) {
   (void)hipDeviceSynchronize();
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->status_host) (void)hipHostFree(h->status_host);
+  for (int i = 0; i < 2; ++i) {
+    if (h->lane_stream[i]) (void)hipStreamDestroy(h->lane_stream[i]);
+    if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+  }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   for (auto& pe : h->prof) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
   delete h;
   return UT_OK;
@@ -613,6 +623,37 @@ int ut_warp_crops(ut_handle h, const uint8_t* src, int n_src_images, int src_h, 
 }
 
 // stem .. projection over crops given as fp32 (crops) or as u8 grey levels (crops_u8)
+// One sub-batch of n crops (workspace slices starting at crop `off`) through stem .. projection on stream st.
+static int backbone_pass(ut_handle h, const float* crops, const uint8_t* crops_u8, int off, int n, float* feat,
+                         hipStream_t st) {
+  int rc;
+  const size_t a48 = (size_t)off * 48 * 48 * 32, a24 = (size_t)off * 24 * 24 * 64, a12 = (size_t)off * 12 * 12 * 128;
+  if (crops_u8) HIPCHK(h, ut::launch_stem_u8(crops_u8, h->stem_w, h->stem_b, h->bufX + a48, n, st));
+  else HIPCHK(h, ut::launch_stem(crops, h->stem_w, h->stem_b, h->bufX + a48, n, st));
+  {
+    float *x = h->bufX + a48, *y = h->bufY + a48;
+    int hw = 48;
+    for (int b = 0; b < 5; ++b) {
+      float* dst = b == 4 ? h->bufL2 + a24 : y;
+      if ((rc = run_block(h, h->bb[b], x, h->bufH + a48, h->bufD + a24, dst, n, hw, hw, st))) return rc;
+      hw = (hw + 2 - 3) / h->bb[b].conv1.stride + 1;
+      float* t = x; x = y; y = t;
+    }
+  }
+  const float* x = h->bufL2 + a24;
+  float *y = h->bufP + a12, *other = h->bufQ + a12;
+  int hw = 24;
+  for (int b = 5; b < 12; ++b) {
+    if ((rc = run_block(h, h->bb[b], x, h->bufBH + a12, h->bufBD + a12, y, n, hw, hw, st))) return rc;
+    hw = (hw + 2 - 3) / h->bb[b].conv1.stride + 1;
+    x = y;
+    float* t = y; y = other; other = t;
+  }
+  // projection 256 -> 72, written NCHW like the reference (lib/models/model_utils.py:134)
+  return run_conv(h, h->proj, x, nullptr, feat, n, 6, 6, false, true, st);
+}
+
+// stem .. projection over crops given as fp32 (crops) or as u8 grey levels (crops_u8)
 static int run_backbone(ut_handle h, const float* crops, const uint8_t* crops_u8, int n_crops, float* feat, hipStream_t s) {
   int rc;
   const int chunk = n_crops < h->chunk ? n_crops : h->chunk;
@@ -620,6 +661,33 @@ static int run_backbone(ut_handle h, const float* crops, const uint8_t* crops_u8
   const int pass_b = n_crops < PHASE_B_MAX ? n_crops : PHASE_B_MAX;
   if ((rc = ensure_phase_b_ws(h, pass_b))) return rc;
   if ((rc = begin_call(h, s))) return rc;
+  // ---- two lanes: the batch fits one pass of both phases and is big enough for two full-chip half-batches.  Every
+  // launch is a persistent grid that drains a tile queue; its last round leaves workgroup slots idle for up to a tile
+  // time (70-140 us of a 1.3 ms launch).  Frames are independent, so the two halves run the same launch sequence on
+  // two streams and each one's idle slots are taken by the other's workgroups.  Same kernels on the same crops: the
+  // results are bit-identical to the single-stream order.  (Not while profiling: per-launch event times would overlap.)
+  if (h->lanes == 2 && !h->profiling && n_crops <= chunk && n_crops <= pass_b && n_crops >= 1024) {
+    if (!h->lane_stream[0]) {
+      for (int i = 0; i < 2; ++i) {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->lane_stream[i], hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+      }
+      HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    }
+    HIPCHK(h, hipEventRecord(h->ev_fork, s));
+    const int n0 = n_crops / 2;
+    for (int i = 0; i < 2; ++i) {
+      const int off = i ? n0 : 0, n = i ? n_crops - n0 : n0;
+      HIPCHK(h, hipStreamWaitEvent(h->lane_stream[i], h->ev_fork, 0));
+      const size_t first = (size_t)off * 96 * 96;
+      if ((rc = backbone_pass(h, crops ? crops + first : nullptr, crops_u8 ? crops_u8 + first : nullptr, off, n,
+                              feat + (size_t)off * 72 * 36, h->lane_stream[i])))
+        return rc;
+      HIPCHK(h, hipEventRecord(h->ev_join[i], h->lane_stream[i]));
+    }
+    for (int i = 0; i < 2; ++i) HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[i], 0));
+    return UT_OK;
+  }
   for (int base = 0; base < n_crops; base += pass_b) {
     const int nb = n_crops - base < pass_b ? n_crops - base : pass_b;
     // ---- phase A: stem + layer1 (48x48x32) + layer2 (24x24x64), `chunk` crops per pass
@@ -866,6 +934,12 @@ int ut_keypoint_metrics(ut_handle h, const float* gt, const float* tracked, cons
   ON_DEVICE_IF(h);
   HIPCHK(h, ut::launch_keypoint_metrics(gt, tracked, valid, n_hands, n_frames, err, acc, gt_acc, valid_acc,
                                         (hipStream_t)stream));
+  return UT_OK;
+}
+
+int ut_set_backbone_lanes(ut_handle h, int lanes) {
+  if (!h || (lanes != 1 && lanes != 2)) return fail(h, UT_E_INVALID, "ut_set_backbone_lanes: 1 or 2");
+  h->lanes = lanes;
   return UT_OK;
 }
 

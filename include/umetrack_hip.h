@@ -75,6 +75,12 @@ int ut_set_index_checks(ut_handle h, int mode);
  * call on this handle since the last poll, else UT_OK. */
 int ut_poll_status(ut_handle h, void* stream);
 
+/* 1 (default) or 2: with 2, a ut_backbone / ut_warp_backbone call of >= 1024 crops that fits one workspace pass runs as
+ * two half-batches on two internal streams (joined to the caller's stream before the call's work is visible to it), so
+ * that the idle tail of one half's launches is filled by the other half's.  Same kernels on the same crops: results
+ * are bit-identical.  Not applied between ut_profile_begin / ut_profile_end. */
+int ut_set_backbone_lanes(ut_handle h, int lanes);
+
 /* Latency mode for calls on a handful of crops (the per-frame tracker): convolutions whose launch has far fewer tiles
  * than the chip has CUs split K across workgroups and add the partial sums in a fixed order.  Deterministic, but not
  * the unsplit kernel's summation order: results agree with the default mode to fp32 rounding (~1e-6 relative), not

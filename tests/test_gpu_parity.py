@@ -347,6 +347,25 @@ def test_latency_mode_matches_the_default_to_rounding(engine):
         fast.close()
 
 
+def test_two_backbone_lanes_are_bit_identical(engine):
+    """ut_set_backbone_lanes(2): a batch of >= 1024 crops runs as two half-batches on two internal streams (each fills
+    the idle tail of the other's launches).  Same kernels on the same crops: same bits, for both crop element types,
+    and the caller's stream sees the joined result (no explicit synchronisation here before the comparison)."""
+    two = _native.HipEngine(synth.synthetic_state_dict(0), DEV)
+    try:
+        two.set_backbone_lanes(2)
+        g = torch.Generator(device=DEV)
+        g.manual_seed(31)
+        for n in (1024, 1501):
+            crops = torch.randint(0, 256, (n, 96, 96), device=DEV, generator=g, dtype=torch.uint8).float() / 255.0
+            want = engine.backbone(crops)
+            got = two.backbone(crops)
+            assert torch.equal(got, want), n
+        assert torch.equal(two.backbone(crops[:700]), want[:700])      # below the threshold: one lane
+    finally:
+        two.close()
+
+
 def _head_inputs(engine, n_samples=3, seed=2):
     n = 2 * n_samples
     g = torch.Generator(device=DEV)
@@ -479,8 +498,8 @@ def test_two_handles_on_one_device_are_independent(engine):
 
 def test_conv_tile_shapes_agree(engine):
     """The convolution dispatch picks its tile shape from the launch size alone (csrc/conv_igemm.hip::launch_conv_igemm):
-    the head's 3x3 / 1x1 convolutions run on 64x128 tiles up to 5 x 256 full-height tiles and on 128x128 tiles beyond
-    (S > 4551 samples), the backbone on 128x64 / 128x128 / the halo-patch kernel by channel count.  Every shape walks K
+    the head's 3x3 / 1x1 convolutions run on 64x128 tiles up to 3 x 256 full-height tiles and on 128x128 tiles beyond
+    (S > 2730 samples), the backbone on 128x64 / 128x128 / the halo-patch kernel by channel count.  Every shape walks K
     in the same order with the same MFMA, so a sample's result must not depend on which shape its batch selected: bit
     for bit, big batch vs the same samples in small batches."""
     s_big = 4800
