@@ -44,8 +44,10 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=768, help="label frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--parity-frames", type=int, default=369,
                     help="label frames of recording_00 run as a sequence against the oracle for mpjpe_delta_mm (0 = skip)")
-    ap.add_argument("--lanes", type=int, default=2, choices=[1, 2],
-                    help="backbone lanes: 2 = two half-batches on two internal streams (ut_set_backbone_lanes)")
+    ap.add_argument("--lanes", type=int, default=1, choices=[1, 2],
+                    help="backbone lanes: 2 = two half-batches on two internal streams (ut_set_backbone_lanes; +0.3 %%, "
+                         "but concurrent launches make per-kernel durations in a rocprof trace overlap, so the default "
+                         "keeps one lane and the trace comparable with the roofline leg)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cropgen-in-step", action="store_true",
                     help="also regenerate the crop cameras from the label poses inside every step (SURVEY 8 f1)")
