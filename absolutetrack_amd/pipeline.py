@@ -351,7 +351,12 @@ def gather_records(local: torch.Tensor, world: int, equal_counts: bool = False) 
 
 def _all_gather_flat(out: torch.Tensor, local: torch.Tensor, world: int) -> None:
     import torch.distributed as dist
-    if dist.get_backend() == "gloo":       # gloo has no all_gather_into_tensor
-        dist.all_gather(list(out.chunk(world, 0)), local)
+    if dist.get_backend() == "gloo":       # gloo has no all_gather_into_tensor, and no all_gather of device tensors
+        if local.device.type == "cuda":
+            host = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather(list(host.chunk(world, 0)), local.cpu())
+            out.copy_(host)
+        else:
+            dist.all_gather(list(out.chunk(world, 0)), local)
     else:
         dist.all_gather_into_tensor(out, local)

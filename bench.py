@@ -48,6 +48,9 @@ def main():
                     help="backbone lanes: 2 = two half-batches on two internal streams (ut_set_backbone_lanes; +0.3 %%, "
                          "but concurrent launches make per-kernel durations in a rocprof trace overlap, so the default "
                          "keeps one lane and the trace comparable with the roofline leg)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend for N>1 (nccl = RCCL over xGMI; gloo only to rehearse the multi-process "
+                         "control flow on a box with fewer GPUs than ranks: ranks then share devices)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cropgen-in-step", action="store_true",
                     help="also regenerate the crop cameras from the label poses inside every step (SURVEY 8 f1)")
@@ -62,12 +65,16 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from absolutetrack_amd import _native, arch, pipeline, synth
 
@@ -99,7 +106,7 @@ def main():
     # (whose read-back would stop the host from running ahead of the GPU)
     equal = True
     if world > 1:
-        c = torch.tensor([s_local, -s_local], dtype=torch.int64, device=device)
+        c = torch.tensor([s_local, -s_local], dtype=torch.int64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(c, op=dist.ReduceOp.MAX)
         equal = int(c[0]) == -int(c[1])
 
@@ -122,7 +129,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     hot.check()            # deferred index checks of every step above
@@ -195,7 +202,8 @@ def main():
                                    + (", crop cameras regenerated in the step" if planner is not None else ""),
                        "frames_per_gpu": f_local, "hand_frames_per_step": s_local * world,
                        "crops_per_step": n_local * world, "src_image": "480x636 u8 x 4 cameras",
-                       "parallelism": f"frame-shard x{world}", "outputs_finite": finite},
+                       "parallelism": f"frame-shard x{world}" + ("" if args.backend == "nccl" else " (gloo rehearsal)"),
+                       "outputs_finite": finite},
             "roofline": roofline, "cpu_baseline": cpu,
             "mpjpe_delta_mm": None if parity is None else parity["mpjpe_delta_mm"], "parity_recording_00": parity,
         }
