@@ -219,7 +219,8 @@ class _Stage:
 
 
 class _LandmarkMemo:
-    """landmarks_from_hand_pose is a pure function of (hand model, pose, hand index); gen_crop_cameras and track_frame
+    """(Process-wide, not thread-safe - like the reference, which runs one tracker per process.)
+    landmarks_from_hand_pose is a pure function of (hand model, pose, hand index); gen_crop_cameras and track_frame
     already run that FK on the GPU for the poses the eval scripts ask about next (run_eval_known_skeleton.py:84-89), so
     they leave the results here.  An entry is used only when the pose arrays and the model tensors are bit-identical."""
 
@@ -522,7 +523,9 @@ class HandTracker:
         if not crop_cameras:
             self.reset_history()       # frame without hands
             return TrackingResult()
-        if self._device == "cuda" and (calibrate or (hand_model is not None and hand_model.joint_rest_positions.dim() == 2)):
+        if self._device == "cuda" and (calibrate or (hand_model is not None and hand_model.joint_rest_positions.dim() == 2
+                                                     and hand_model.joint_rest_positions.device.type == "cpu"
+                                                     and hand_model.joint_rotation_axes.device.type == "cpu")):
             res = self._run_staged(sample, hand_model, crop_cameras, calibrate)
             if res is not None:
                 return res
