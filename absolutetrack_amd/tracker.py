@@ -222,14 +222,15 @@ class _LandmarkMemo:
     """(Process-wide, not thread-safe - like the reference, which runs one tracker per process.)
     landmarks_from_hand_pose is a pure function of (hand model, pose, hand index); gen_crop_cameras and track_frame
     already run that FK on the GPU for the poses the eval scripts ask about next (run_eval_known_skeleton.py:84-89), so
-    they leave the results here.  An entry is used only when the pose arrays and the model tensors are bit-identical."""
+    they leave the results here.  An entry is used only when the pose arrays are bit-identical and the model tensors are
+    the same objects at the same in-place version."""
 
     def __init__(self, cap: int = 16):
         self.cap = cap
         self.items = []       # (model tensors, hand_idx, joint_angles f32[22], wrist f32[4,4], landmarks [21,3])
 
     def put(self, hand_model, hand_idx, ja, xf, kp):
-        self.items.insert(0, (tuple(getattr(hand_model, f) for f in _MEMO_FIELDS), int(hand_idx),
+        self.items.insert(0, (tuple((t, t._version) for t in (getattr(hand_model, f) for f in _MEMO_FIELDS)), int(hand_idx),
                               np.array(ja, np.float32), np.array(xf, np.float32), np.array(kp, np.float32)))
         del self.items[self.cap:]
 
@@ -239,7 +240,7 @@ class _LandmarkMemo:
             return None
         for model, h, j, x, kp in self.items:
             if h == int(hand_idx) and np.array_equal(j, ja32) and np.array_equal(x, xf32) and \
-                    all(a is b for a, b in zip(model, (getattr(hand_model, f) for f in _MEMO_FIELDS))):
+                    all(a is b and v == b._version for (a, v), b in zip(model, (getattr(hand_model, f) for f in _MEMO_FIELDS))):
                 return kp.copy()
         return None
 

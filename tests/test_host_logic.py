@@ -298,3 +298,25 @@ def test_boundary_header_is_plain_c_and_callable_from_c(tmp_path):
     out = subprocess.run([exe, _native.LIB_PATH], capture_output=True, text=True)
     assert out.returncode == 0, (out.returncode, out.stderr)
     assert int(out.stdout.strip()) == sum(int(np.prod(s)) for _k, s, _kind in arch.state_dict_spec())
+
+
+def test_landmark_memo_is_exact_and_invalidates():
+    """The per-frame tracker remembers FK results for landmarks_from_hand_pose (tracker._LandmarkMemo): an entry is
+    served only for the same model tensors (same objects, same in-place version), the same hand and bit-identical pose
+    arrays (compared as float32, the precision the FK kernel sees)."""
+    from absolutetrack_amd import tracker as tk
+    hm = pipeline.hand_model_from_labels(pipeline.load_labels())
+    m = tk._LandmarkMemo(cap=2)
+    ja, xf = np.linspace(0, 1, 22), np.eye(4)
+    kp = np.arange(63, dtype=np.float32).reshape(21, 3)
+    m.put(hm, 1, ja, xf, kp)
+    got = m.get(hm, 1, ja.astype(np.float32), xf.astype(np.float32))
+    assert np.array_equal(got, kp) and got is not kp
+    assert m.get(hm, 0, ja, xf) is None                                   # other hand
+    assert m.get(hm, 1, ja + 1e-6, xf) is None                            # other pose
+    other = hm._replace(joint_rest_positions=hm.joint_rest_positions.clone())
+    assert m.get(other, 1, ja, xf) is None                                # other model tensors
+    hm.joint_rest_positions.mul_(1.0)                                     # same object, new in-place version
+    assert m.get(hm, 1, ja, xf) is None
+    m.put(hm, 1, ja, xf, kp); m.put(hm, 0, ja, xf, kp); m.put(hm, 1, ja + 1, xf, kp)
+    assert len(m.items) == 2 and m.get(hm, 1, ja, xf) is None             # capacity: oldest entry dropped
