@@ -1,0 +1,452 @@
+// Split-bf16 implicit-GEMM convolution for gfx950: fp32 results from the bf16 matrix cores.
+//
+// An fp32 value is the exact sum of three bf16 pieces (8 + 8 + 8 significand bits: hi = the top half of the fp32 word,
+// mid = the top half of x - hi, lo = x - hi - mid), a product of two bf16 values is exact in fp32, and
+// v_mfma_f32_32x32x16_bf16 accumulates in fp32.  Six of the nine piece products,
+//     x0 w0 + x0 w1 + x1 w0 + x1 w1 + x0 w2 + x2 w0 ,
+// drop only terms below 2^-24 of the full product - the rounding error of one fp32 multiply - so a convolution built
+// from them carries fp32-level error (oracle/studies/split_precision.py: 2.4e-7 rad at the joint angles, the same as a
+// change of summation order) while the matrix pipe needs 6 x 32 cycles per 16 k instead of 16 x 64 / 2 = 512:
+// 2.67x the rate of v_mfma_f32_32x32x2_f32.  Same layers as conv_igemm.hip (lib/models/backbone_resnet.py:56-72),
+// same NHWC fp32 tensors in HBM; only the arithmetic inside the kernel changes.
+//
+// Activations stay fp32 in HBM and in LDS and are split in registers after the fragment read (4 VALU per value + 3
+// v_perm per pair; the weights' pieces are made once on the host and stored as bf16 planes in fragment order, so a
+// wave reads a weight fragment with one conflict-free ds_read_b128 per (32 rows, 16 k, plane)).
+//
+// One workgroup of 8 waves per CU computes 256 x BN output tiles, K in chunks of 32 (two MFMA k-steps).  Operands go
+// global -> LDS by LDS-DMA into rings: 3 stages of pixels (im2col gather, XOR-swizzled 128-byte rows as in
+// conv_igemm.hip), 2 stages of weights (L2 resident, shorter latency).  One barrier per chunk, early in its first
+// k-step: at that point every fragment of the chunk is in registers, so the barrier both publishes the next chunk and
+// frees the current chunk's buffers, into which the transfers for two (weights) and three (pixels) chunks ahead are
+// issued right behind it; the wait in front of the barrier is a counted vmcnt that leaves the youngest pixel pieces in
+// flight.  Persistent grid with the same tile queue as conv_igemm.hip; the fetch side runs across tile boundaries.
+// Epilogue: bias + residual + ReLU + 16-byte NHWC stores (the accumulator layout of the 32x32 MFMAs is the same as in
+// conv_igemm.hip: a lane owns one pixel, register quads are 4 consecutive channels).
+#include <atomic>
+
+#include "ut_kernels.h"
+
+namespace ut {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) char lds_char;
+
+constexpr unsigned OOB = 0xFFFFFF00u;
+
+// LDS-DMA piece (see conv_igemm.hip::dma16): per-lane byte offset + wave-uniform byte offset
+__device__ __forceinline__ void dma_piece(u32x4 rsrc, unsigned lds_addr, unsigned voffset, unsigned soffset) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voffset), "s"(lds_addr), "s"(rsrc), "s"(soffset)
+      : "memory");
+}
+__device__ __forceinline__ u32x4 rsrc_words(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  u32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+  r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xFFFFu);
+  r.z = __builtin_amdgcn_readfirstlane(bytes);
+  r.w = 0x00020000u;
+  return r;
+}
+__device__ __forceinline__ int fdiv(int n, int d, float inv_d) {
+  int q = (int)((float)n * inv_d);
+  int r = n - q * d;
+  if (r < 0) --q;
+  if (r >= d) ++q;
+  return q;
+}
+
+// two fp32 values -> their (hi, mid, lo) bf16 pieces, packed {second, first} per plane
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+  const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+  const float ra = a - __uint_as_float(ua & 0xFFFF0000u), rb = b - __uint_as_float(ub & 0xFFFF0000u);
+  const unsigned uar = __float_as_uint(ra), ubr = __float_as_uint(rb);
+  const float la = ra - __uint_as_float(uar & 0xFFFF0000u), lb = rb - __uint_as_float(ubr & 0xFFFF0000u);
+  hi = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+  mid = __builtin_amdgcn_perm(ubr, uar, 0x07060302u);
+  lo = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), 0x07060302u);
+}
+__device__ __forceinline__ bf16x8 frag(const unsigned (&v)[4]) {
+  u32x4 t;
+  t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+  return __builtin_bit_cast(bf16x8, t);
+}
+
+template <int BM, int BN, int WR, int WC>
+__global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int tiles_n, int n_tiles) {
+  static_assert(WR * WC == 8, "8 waves per workgroup");
+  constexpr int MI = BM / WR / 32, NI = BN / WC / 32;
+  constexpr int AP = BM / 64;              // pixel pieces per wave per chunk (a piece = 8 rows x 128 B)
+  constexpr int WTOT = BN / 32 * 6;        // 1-KB weight blocks per chunk: (32 rows) x (k-step) x (plane)
+  constexpr int WP = (WTOT + 7) / 8;       // ... per wave
+  constexpr int A_STAGE = BM * 128, W_STAGE = BN * 192;
+  constexpr int A_RING = 3, W_RING = 2;
+  constexpr int W_BASE = A_RING * A_STAGE;
+  constexpr int SLOT = W_BASE + W_RING * W_STAGE;
+  constexpr int NM = 6 * MI * NI;          // MFMAs per k-step
+  constexpr int UNITS = MI * 4;            // pair conversions per k-step
+  constexpr int CSTEP = (NM - 6) / UNITS;  // one every CSTEP MFMAs, from slot 4
+  static_assert(CSTEP >= 1, "room for the conversions");
+  constexpr int ASL = 4 + WP + 2 * AP <= NM ? 2 : 1;   // MFMA slots per pixel piece (offset and transfer apart if there is room)
+  static_assert(4 + WP + ASL * AP <= NM, "room for the transfers");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WC, wn = wave % WC;
+  const int g = tid & 7;
+  const int r0 = tid >> 3;                  // 0..63: pixel row this thread stages (then +64 per piece)
+  const int gk = g ^ ((r0 >> 1) & 7);       // which 16-byte group of the 128-byte k chunk lands at position g
+  const int fr = lane & 31, fh = lane >> 5;
+
+  const int M = p.n_img * p.Ho * p.Wo;
+  const int hw = p.Ho * p.Wo;
+  const float inv_hw = 1.0f / (float)hw, inv_wo = 1.0f / (float)p.Wo;
+  const int taps = p.ksize * p.ksize;
+  const int n_chunks = p.k_pad / 32;
+
+  const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.res ? p.res : p.bias), 0, p.res ? (int)((size_t)M * p.cout_store * sizeof(float)) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t o_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((size_t)M * p.cout_store * sizeof(float)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t q_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.tile_counter, 0, 4, 0x00020000);
+  const unsigned q_off = tid == 0 ? 0u : OOB;
+  const u32x4 a_words = rsrc_words(p.in, (unsigned)((size_t)p.n_img * p.H * p.W * p.cin * sizeof(float)));
+  const u32x4 w_words = rsrc_words(p.w_split, (unsigned)((size_t)(p.cout_pad / 32) * n_chunks * 6144));
+  const unsigned smem_addr = (unsigned)(unsigned long)(lds_char*)smem;
+
+  const int grid = gridDim.x;
+  int slot = blockIdx.x;
+  if ((grid & 7) == 0) slot = (blockIdx.x & 7) * (grid >> 3) + (blockIdx.x >> 3);
+
+  // ---- fetch side: the pixel stream runs three chunks ahead of the MFMAs, the weight stream two
+  int fa_tile = slot, fa_c = 0, fa_tap = 0, fa_chb = 0;      // pixel stream: tile, chunk, tap, channel-slice base
+  unsigned fa_stage = 0;                                      // byte offset of the ring stage it writes next
+  int a_pix[AP], a_iy[AP], a_ix[AP];
+  int fw_tile = slot, fw_c = 0;
+  unsigned fw_stage = 0;
+  unsigned fw_row;                                            // byte offset of (tile column, chunk 0) of this wave's first block
+  const unsigned w_lane = (unsigned)lane * 16u;
+  int next_tile = 0;                                          // the tile after the one being computed (valid once read)
+
+#define SP_A_SETUP()                                                                                 \
+  {                                                                                                  \
+    const int tm_ = fa_tile / tiles_n;                                                               \
+    _Pragma("unroll") for (int i = 0; i < AP; ++i) {                                                 \
+      const int m = tm_ * BM + r0 + 64 * i;                                                          \
+      const bool ok = m < M && fa_tile < n_tiles;                                                    \
+      const int mm = ok ? m : 0;                                                                     \
+      const int img = fdiv(mm, hw, inv_hw);                                                          \
+      const int rem = mm - img * hw;                                                                 \
+      const int oy = fdiv(rem, p.Wo, inv_wo), ox = rem - oy * p.Wo;                                  \
+      a_iy[i] = ok ? oy * p.stride - p.pad : -100000;                                                \
+      a_ix[i] = ox * p.stride - p.pad;                                                               \
+      a_pix[i] = ((img * p.H + a_iy[i]) * p.W + a_ix[i]) * p.cin + 4 * gk;                           \
+    }                                                                                                \
+    fa_c = 0; fa_tap = 0; fa_chb = 0;                                                                \
+  }
+#define SP_W_SETUP()                                                                                 \
+  {                                                                                                  \
+    const int tn_ = fw_tile - (fw_tile / tiles_n) * tiles_n;                                         \
+    fw_row = (unsigned)(tn_ * (BN / 32)) * (unsigned)n_chunks * 6144u;                               \
+    fw_c = 0;                                                                                        \
+  }
+  // one pixel piece of the fetch chunk: per-lane offset, then the transfer
+  int f_dy = 0, f_dx = 0, f_tap_off = 0;   // tap of the pixel stream's chunk (wave-uniform)
+#define SP_A_TAP()                                                                                   \
+  {                                                                                                  \
+    f_dy = 0; f_dx = 0;                                                                              \
+    if (p.ksize == 3) { f_dy = (fa_tap * 11) >> 5; f_dx = fa_tap - 3 * f_dy; }                       \
+    f_tap_off = (f_dy * p.W + f_dx) * p.cin + fa_chb;                                                \
+  }
+#define SP_A_ADDR(I, OFF)                                                                            \
+  {                                                                                                  \
+    const int iy = a_iy[I] + f_dy, ix = a_ix[I] + f_dx;                                              \
+    const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;                    \
+    OFF = ok ? (unsigned)(a_pix[I] + f_tap_off) * 4u : OOB;                                          \
+  }
+#define SP_A_ISSUE(I, OFF) dma_piece(a_words, smem_addr + fa_stage + (unsigned)((64 * (I) + 8 * wave) * 128), OFF, 0u)
+#define SP_A_ADVANCE()                                                                               \
+  {                                                                                                  \
+    fa_stage = fa_stage + A_STAGE == A_RING * A_STAGE ? 0u : fa_stage + A_STAGE;                     \
+    ++fa_c; ++fa_tap;                                                                                \
+    if (fa_tap >= taps) { fa_tap = 0; fa_chb += 32; }                                                \
+  }
+  // weight block T of this wave: block q = wave * WP + T of the chunk image; group q / 6 of the tile column
+#define SP_W_ISSUE(T)                                                                                \
+  {                                                                                                  \
+    const int q_ = wave * WP + (T);                                                                  \
+    if (WTOT % 8 == 0 || q_ < WTOT) {                                                                \
+      const unsigned src_ = fw_row + (unsigned)((q_ / 6) * n_chunks + fw_c) * 6144u + (unsigned)(q_ % 6) * 1024u; \
+      dma_piece(w_words, smem_addr + W_BASE + fw_stage + (unsigned)q_ * 1024u, w_lane, src_);        \
+    }                                                                                                \
+  }
+#define SP_W_ADVANCE() { fw_stage ^= W_STAGE; ++fw_c; }
+
+  // ---- compute side
+  f32x16 acc[MI][NI];
+  unsigned xp[2][MI][3][4];      // pixel fragments, pieces (hi, mid, lo), two k-steps in flight
+  unsigned wf[2][NI][3][4];      // weight fragments
+  float4 xr[MI][2];              // raw fp32 pixels of the k-step being converted
+  unsigned rd_a = 0, rd_w = 0;   // ring stages being read
+  // per-lane read offsets: pixel row fr of the wave's rows, 16-byte positions (4s + 2fh + h) ^ swizzle
+  const unsigned x_row = (unsigned)((wm * MI * 32 + fr) * 128);
+  unsigned x_pos[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) x_pos[s][h] = (unsigned)(((4 * s + 2 * fh + h) ^ ((fr >> 1) & 7)) * 16);
+  const unsigned w_rd = (unsigned)(W_BASE + wn * NI * 6 * 1024) + w_lane;
+
+#define SP_READ(SET, S, A_ST, W_ST)                                                                  \
+  {                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
+      _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                  \
+        xr[i][h] = *reinterpret_cast<const float4*>(smem + (A_ST) + x_row + i * 4096 + x_pos[S][h]); \
+    _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                   \
+      _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                                             \
+        const u32x4 t_ = *reinterpret_cast<const u32x4*>(smem + w_rd + (W_ST) + ((j * 2 + (S)) * 3 + pl) * 1024); \
+        wf[SET][j][pl][0] = t_.x; wf[SET][j][pl][1] = t_.y; wf[SET][j][pl][2] = t_.z; wf[SET][j][pl][3] = t_.w; \
+      }                                                                                              \
+  }
+  // conversion unit U of a k-step: pair (U & 3) of row fragment U >> 2
+#define SP_CONV(SET, U)                                                                              \
+  {                                                                                                  \
+    constexpr int i_ = (U) >> 2, pr_ = (U) & 3;                                                      \
+    const float4 v_ = xr[i_][pr_ >> 1];                                                              \
+    if constexpr ((pr_ & 1) == 0) split_pair(v_.x, v_.y, xp[SET][i_][0][pr_], xp[SET][i_][1][pr_], xp[SET][i_][2][pr_]); \
+    else split_pair(v_.z, v_.w, xp[SET][i_][0][pr_], xp[SET][i_][1][pr_], xp[SET][i_][2][pr_]);     \
+  }
+#define SP_PIN() __builtin_amdgcn_sched_barrier(0)
+  // MFMA N of a k-step: products (weight plane, pixel plane) small terms first, accumulators round-robin inside a product
+#define SP_MFMA(SET, N)                                                                              \
+  {                                                                                                  \
+    constexpr int pr_ = (N) / (MI * NI), ij_ = (N) % (MI * NI), i_ = ij_ / NI, j_ = ij_ % NI;        \
+    constexpr int wp_ = pr_ == 0 ? 0 : pr_ == 1 ? 2 : pr_ == 2 ? 1 : pr_ == 3 ? 0 : pr_ == 4 ? 1 : 0; \
+    constexpr int xp_ = pr_ == 0 ? 2 : pr_ == 1 ? 0 : pr_ == 2 ? 1 : pr_ == 3 ? 1 : pr_ == 4 ? 0 : 0; \
+    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(wf[SET][j_][wp_]), frag(xp[SET][i_][xp_]), acc[i_][j_], 0, 0, 0); \
+  }
+
+  // One k-step.  CUR: register set consumed, NXT: set filled for the following step (read at slot 0 from stages
+  // RA / RW, k-step RS of that chunk).  FIRST: the chunk's first step, which carries the barrier and the transfers.
+#define SP_SLOT(CUR, NXT, N, FIRST)                                                                  \
+  {                                                                                                  \
+    if constexpr (FIRST && (N) == 3) {                                                               \
+      if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    \
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP) : "memory");                                 \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+      __builtin_amdgcn_s_barrier();                                                                  \
+      drain = false;                                                                                 \
+      /* the ticket taken at the tile's start is older than every transfer still in flight here */    \
+      if (c == 1 && tid == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(slot_addr), "v"(grid + ticket) : "memory"); \
+    }                                                                                                \
+    if constexpr (FIRST && (N) >= 4 && (N) < 4 + WP) SP_W_ISSUE((N) - 4);                            \
+    if constexpr (FIRST && (N) >= 4 + WP && (N) < 4 + WP + ASL * AP) {                               \
+      constexpr int k_ = (N) - 4 - WP;                                                               \
+      if constexpr (ASL == 1) { SP_A_ADDR(k_, a_off); SP_A_ISSUE(k_, a_off); }                       \
+      else if constexpr ((k_ & 1) == 0) { SP_A_ADDR(k_ >> 1, a_off); } else { SP_A_ISSUE(k_ >> 1, a_off); } \
+    }                                                                                                \
+    if constexpr ((N) >= 4 && ((N) - 4) % CSTEP == 0 && ((N) - 4) / CSTEP < UNITS) SP_CONV(NXT, ((N) - 4) / CSTEP); \
+    SP_PIN();                                                                                        \
+    SP_MFMA(CUR, N);                                                                                 \
+    SP_PIN();                                                                                        \
+  }
+#define SP_SLOTS4(CUR, NXT, N, FIRST) SP_SLOT(CUR, NXT, N, FIRST) SP_SLOT(CUR, NXT, (N) + 1, FIRST) SP_SLOT(CUR, NXT, (N) + 2, FIRST) SP_SLOT(CUR, NXT, (N) + 3, FIRST)
+#define SP_STEP(CUR, NXT, FIRST)                                                                     \
+  {                                                                                                  \
+    SP_SLOTS4(CUR, NXT, 0, FIRST) SP_SLOTS4(CUR, NXT, 4, FIRST) SP_SLOTS4(CUR, NXT, 8, FIRST)        \
+    if constexpr (NM > 12) { SP_SLOTS4(CUR, NXT, 12, FIRST) SP_SLOTS4(CUR, NXT, 16, FIRST) SP_SLOTS4(CUR, NXT, 20, FIRST) } \
+  }
+
+  const unsigned slot_addr = smem_addr + (unsigned)SLOT;
+  // ---- prologue: chunks 0 and 1 of the first tile and the pixels of chunk 2
+  SP_A_SETUP();
+  SP_W_SETUP();
+  unsigned a_off = 0;
+  bool drain = false;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    SP_A_TAP();
+#pragma unroll
+    for (int i = 0; i < AP; ++i) { SP_A_ADDR(i, a_off); SP_A_ISSUE(i, a_off); }
+    SP_A_ADVANCE();
+    if (c < 2) {
+#pragma unroll
+      for (int t = 0; t < WP; ++t) SP_W_ISSUE(t);
+      SP_W_ADVANCE();
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  SP_READ(0, 0, 0u, 0u);
+  SP_CONV(0, 0) SP_CONV(0, 1) SP_CONV(0, 2) SP_CONV(0, 3)
+  if constexpr (UNITS > 4) { SP_CONV(0, 4) SP_CONV(0, 5) SP_CONV(0, 6) SP_CONV(0, 7) }
+
+  int tile = slot;
+  for (;;) {
+    const int ticket = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, q_rsrc, q_off, 0, 0);
+    for (int c = 0; c < n_chunks; ++c) {
+      // tile hand-over of the streams: the weight stream enters the next tile two chunks before the MFMAs do, the
+      // pixel stream three (the queue slot was written during chunk 1 and published by the barriers since)
+      if (c == n_chunks - 3) {
+        int nv;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nv) : "v"(slot_addr) : "memory");
+        next_tile = __builtin_amdgcn_readfirstlane(nv);
+        fa_tile = next_tile;
+        SP_A_SETUP();
+      }
+      if (c == n_chunks - 2) { fw_tile = next_tile; SP_W_SETUP(); }
+      SP_A_TAP();
+      // first k-step: set 0; its slot 0 reads the second k-step of the same chunk into set 1
+      SP_READ(1, 1, rd_a, rd_w);
+      SP_STEP(0, 1, true)
+      SP_A_ADVANCE();
+      SP_W_ADVANCE();
+      // second k-step: set 1; reads the first k-step of the next chunk (published by this chunk's barrier) into set 0
+      rd_a = rd_a + A_STAGE == A_RING * A_STAGE ? 0u : rd_a + A_STAGE;
+      rd_w ^= W_STAGE;
+      SP_READ(0, 0, rd_a, rd_w);
+      SP_STEP(1, 0, false)
+    }
+    // ---- epilogue: bias + residual + ReLU + store
+    {
+      const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+      const float floor_v = p.relu ? 0.f : -__builtin_huge_valf();
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = tm * BM + wm * (MI * 32) + i * 32 + fr;
+        const bool m_ok = m < M;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          u32x4 rr[4];
+          float4 bb[4];
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int n = tn * BN + wn * (NI * 32) + j * 32 + 8 * g4 + 4 * fh;
+            const unsigned off = (m_ok && n < p.cout_store) ? (unsigned)(m * p.cout_store + n) * 4u : OOB;
+            rr[g4] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0);
+            bb[g4] = *reinterpret_cast<const float4*>(p.bias + n);
+          }
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int n = tn * BN + wn * (NI * 32) + j * 32 + 8 * g4 + 4 * fh;
+            const unsigned off = (m_ok && n < p.cout_store) ? (unsigned)(m * p.cout_store + n) * 4u : OOB;
+            u32x4 pk;
+            pk.x = __float_as_uint(fmaxf(acc[i][j][4 * g4 + 0] + bb[g4].x + __uint_as_float(rr[g4].x), floor_v));
+            pk.y = __float_as_uint(fmaxf(acc[i][j][4 * g4 + 1] + bb[g4].y + __uint_as_float(rr[g4].y), floor_v));
+            pk.z = __float_as_uint(fmaxf(acc[i][j][4 * g4 + 2] + bb[g4].z + __uint_as_float(rr[g4].z), floor_v));
+            pk.w = __float_as_uint(fmaxf(acc[i][j][4 * g4 + 3] + bb[g4].w + __uint_as_float(rr[g4].w), floor_v));
+            __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, off, 0, 0);
+          }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        }
+      }
+      drain = true;     // stores complete out of order with the transfers: the next barrier waits for everything
+    }
+    if (next_tile >= n_tiles) break;
+    tile = next_tile;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the transfers issued for tiles that do not exist
+#undef SP_A_SETUP
+#undef SP_W_SETUP
+#undef SP_A_TAP
+#undef SP_A_ADDR
+#undef SP_A_ISSUE
+#undef SP_A_ADVANCE
+#undef SP_W_ISSUE
+#undef SP_W_ADVANCE
+#undef SP_READ
+#undef SP_CONV
+#undef SP_PIN
+#undef SP_MFMA
+#undef SP_SLOT
+#undef SP_SLOTS4
+#undef SP_STEP
+}
+
+template <int BM, int BN, int WR, int WC>
+hipError_t launch_split_cfg(const ConvLaunch& c, hipStream_t s) {
+  const int M = c.n_img * c.Ho * c.Wo;
+  const int tiles_m = (M + BM - 1) / BM;
+  const int tiles_n = (c.cout_store + BN - 1) / BN;
+  const int n_tiles = tiles_m * tiles_n;
+  const size_t lds = 3 * (size_t)BM * 128 + 2 * (size_t)BN * 192 + 16;
+  static std::atomic<unsigned long long> attr_set{0};
+  const unsigned long long dev_bit = (c.device >= 0 && c.device < 64) ? 1ull << c.device : 0ull;
+  if (!(attr_set.load(std::memory_order_relaxed) & dev_bit) || !dev_bit) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<BM, BN, WR, WC>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set.fetch_or(dev_bit, std::memory_order_relaxed);
+  }
+  int grid = c.num_cu;
+  if (grid > n_tiles) grid = n_tiles;
+  hipLaunchKernelGGL((conv_split_kernel<BM, BN, WR, WC>), dim3(grid), dim3(512), lds, s, c, tiles_n, n_tiles);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool conv_split_applicable(const ConvLaunch& c) {
+  return c.w_split && c.cslice == 32 && c.cin % 32 == 0 && !c.out_nchw && c.splits == 0 && c.k_pad / 32 >= 6 &&
+         c.cout_store % 4 == 0 && c.cout_store >= 64 && c.tile_counter && c.num_cu > 0;
+}
+
+hipError_t launch_conv_split(const ConvLaunch& c, hipStream_t s) {
+  if (!conv_split_applicable(c)) return hipErrorInvalidValue;
+  if ((size_t)c.n_img * c.H * c.W * c.cin * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
+  if ((size_t)c.n_img * c.Ho * c.Wo * c.cout_store * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
+  if (c.cout_store <= 64) return launch_split_cfg<256, 64, 8, 1>(c, s);
+  return launch_split_cfg<256, 128, 4, 2>(c, s);
+}
+
+// Host side: the three bf16 planes of the packed fp32 weights [cout_pad][k_pad] in fragment order:
+// [cout_pad / 32][k_pad / 32][k-step 2][plane 3][lane 64][8] bf16, lane = (row & 31) + 32 * half, element e of the
+// lane = k 16 * step + 8 * half + e of the chunk.  Returns the number of 16-bit words (= 3 * cout_pad * k_pad).
+size_t pack_split_weights(const float* w, int cout_pad, int k_pad, uint16_t* out) {
+  const int n_chunks = k_pad / 32;
+  for (int grp = 0; grp < cout_pad / 32; ++grp)
+    for (int kc = 0; kc < n_chunks; ++kc)
+      for (int st = 0; st < 2; ++st)
+        for (int ln = 0; ln < 64; ++ln)
+          for (int e = 0; e < 8; ++e) {
+            const float x = w[(size_t)(grp * 32 + (ln & 31)) * k_pad + kc * 32 + 16 * st + 8 * (ln >> 5) + e];
+            uint32_t u;
+            __builtin_memcpy(&u, &x, 4);
+            const uint32_t uh = u & 0xFFFF0000u;
+            float fh_;
+            __builtin_memcpy(&fh_, &uh, 4);
+            const float r = x - fh_;
+            uint32_t ur;
+            __builtin_memcpy(&ur, &r, 4);
+            const uint32_t um = ur & 0xFFFF0000u;
+            float fm;
+            __builtin_memcpy(&fm, &um, 4);
+            const float l = r - fm;
+            uint32_t ul;
+            __builtin_memcpy(&ul, &l, 4);
+            const size_t base = ((((size_t)grp * n_chunks + kc) * 2 + st) * 3) * 512 + (size_t)ln * 8 + e;
+            out[base] = (uint16_t)(uh >> 16);
+            out[base + 512] = (uint16_t)(um >> 16);
+            out[base + 1024] = (uint16_t)(ul >> 16);
+          }
+  return (size_t)3 * cout_pad * k_pad;
+}
+
+}  // namespace ut

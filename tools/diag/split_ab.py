@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Diagnostic (not part of the product): the split-bf16 convolution (conv_split.hip) against the fp32-MFMA one
+(conv_igemm.hip) on one layer shape - error of both against a float64 convolution of the first images, and interleaved timing.
+    python tools/diag/split_ab.py <cin> <cout> <hw> <n_img> [ksize] [stride]"""
+import ctypes
+import os
+import statistics
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+CSRC = os.path.join(ROOT, "absolutetrack_amd", "csrc")
+cin, cout, hw, n_img = (int(a) for a in sys.argv[1:5])
+ksize = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+stride = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+so = "/tmp/libsplitab.so"
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w", "-o", so,
+                       os.path.join(CSRC, "conv_igemm.hip"), os.path.join(CSRC, "conv_patch.hip"), os.path.join(CSRC, "conv_split.hip"),
+                       os.path.join(ROOT, "tools", "diag", "split_entry.hip"), "-I", CSRC])
+lib = ctypes.CDLL(so)
+dev = "cuda:0"
+torch.manual_seed(0)
+ho = (hw + 2 * (ksize // 2) - ksize) // stride + 1
+x = torch.rand(n_img, hw, hw, cin, device=dev) * 2 - 0.5
+k_total = ksize * ksize * cin
+cout_pad = 128 * ((cout + 127) // 128)
+w_oihw = torch.randn(cout, cin, ksize, ksize) * (2.0 / (ksize * ksize * cout)) ** 0.5
+# packed k order (channel slice of 32, tap, channel in slice)
+wp = torch.zeros(cout_pad, k_total)
+wp[:cout] = w_oihw.reshape(cout, cin // 32, 32, ksize * ksize).permute(0, 1, 3, 2).reshape(cout, k_total)
+bias = torch.zeros(cout_pad)
+bias[:cout] = torch.randn(cout) * 0.1
+res = torch.rand(n_img, ho, ho, cout, device=dev)
+split = np.zeros(3 * cout_pad * k_total, np.uint16)
+assert lib.split_pack(wp.numpy().ctypes.data_as(ctypes.c_void_p), cout_pad, k_total, split.ctypes.data_as(ctypes.c_void_p)) == 0
+w_d, b_d = wp.to(dev), bias.to(dev)
+s_d = torch.from_numpy(split.view(np.int16)).to(dev)
+out = torch.empty(n_img, ho, ho, cout, device=dev)
+
+
+def run(mode):
+    rc = lib.conv_diag2(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(w_d.data_ptr()), ctypes.c_void_p(s_d.data_ptr()),
+                        ctypes.c_void_p(b_d.data_ptr()), ctypes.c_void_p(res.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                        n_img, hw, cin, cout, ksize, stride, 1, mode)
+    assert rc == 0, rc
+
+
+nref = min(n_img, 6)
+ref = torch.nn.functional.conv2d(x[:nref].permute(0, 3, 1, 2).double().cpu(), w_oihw.double(), bias[:cout].double(), stride, ksize // 2)
+ref = torch.relu(ref.permute(0, 2, 3, 1) + res[:nref].double().cpu())
+outs = {}
+for mode, name in ((0, "fp32 mfma"), (1, "split bf16x6")):
+    out.fill_(float("nan"))
+    run(mode)
+    torch.cuda.synchronize()
+    o = out.clone()
+    outs[name] = o
+    assert torch.isfinite(o).all(), name
+    print(f"{name:14s} max |out - f64 conv| over {nref} images = {float((o[:nref].double().cpu() - ref).abs().max()):.3e}")
+a, b = outs["fp32 mfma"], outs["split bf16x6"]
+print(f"max |split - fp32| over all {n_img} images = {float((a - b).abs().max()):.3e}   (|out| max {float(a.abs().max()):.2f})")
+flops = 2.0 * n_img * ho * ho * cout * k_total
+times = {0: [], 1: []}
+for rnd in range(10):
+    for mode in (0, 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            run(mode)
+        e1.record()
+        torch.cuda.synchronize()
+        times[mode].append(e0.elapsed_time(e1) / 4)
+for mode, name in ((0, "fp32 mfma"), (1, "split bf16x6")):
+    t = times[mode]
+    med, mn = statistics.median(t), min(t)
+    print(f"{name:14s} median {med*1e3:8.1f} us ({flops/med/1e9:6.1f} TF-equivalent)   min {mn*1e3:8.1f} us ({flops/mn/1e9:6.1f})")

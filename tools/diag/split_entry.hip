@@ -1,0 +1,26 @@
+// Diagnostic entry (not part of libumetrack_hip.so): one convolution through launch_conv_igemm (mode 0) or
+// launch_conv_split (mode 1), and the host-side weight split.
+#include <vector>
+
+#include "ut_kernels.h"
+
+extern "C" int split_pack(const float* w, int cout_pad, int k_pad, uint16_t* out) {
+  return (int)(ut::pack_split_weights(w, cout_pad, k_pad, out) != (size_t)3 * cout_pad * k_pad);
+}
+
+extern "C" int conv_diag2(const float* in, const float* w, const void* w_split, const float* bias, const float* res,
+                          float* out, int n_img, int hw, int cin, int cout, int ksize, int stride, int relu, int mode) {
+  ut::ConvLaunch c{};
+  c.in = in; c.w = w; c.w_split = w_split; c.bias = bias; c.res = res; c.out = out;
+  c.n_img = n_img; c.H = hw; c.W = hw; c.cin = cin;
+  c.ksize = ksize; c.stride = stride; c.pad = ksize / 2;
+  c.Ho = (hw + 2 * c.pad - ksize) / stride + 1; c.Wo = c.Ho;
+  c.cout_store = cout; c.cout_pad = (cout + 127) / 128 * 128; c.k_total = ksize * ksize * cin; c.k_pad = c.k_total;
+  c.cslice = cin % 32 == 0 ? 32 : cin; c.relu = relu; c.out_nchw = 0;
+  c.num_cu = 256; c.device = 0;
+  static unsigned* cnt = nullptr;
+  if (!cnt) (void)hipMalloc((void**)&cnt, 4);
+  (void)hipMemsetAsync(cnt, 0, 4, 0);
+  c.tile_counter = cnt;
+  return (int)(mode ? ut::launch_conv_split(c, 0) : ut::launch_conv_igemm(c, 0));
+}
