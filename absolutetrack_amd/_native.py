@@ -21,7 +21,7 @@ EXPORTS = (
     "ut_set_backbone_chunk", "ut_warp_crops", "ut_backbone", "ut_fuse_temporal_regress",
     "ut_reset_memory", "ut_get_memory", "ut_fk", "ut_gen_crop_cameras", "ut_gen_crop_matrices",
     "ut_resample_homography", "ut_keypoint_metrics", "ut_profile_begin", "ut_profile_end",
-    "ut_set_index_checks", "ut_poll_status", "ut_warp_backbone", "ut_set_latency_mode",
+    "ut_set_index_checks", "ut_poll_status", "ut_warp_backbone", "ut_set_latency_mode", "ut_set_conv_arithmetic",
     "ut_set_backbone_lanes",
 )
 
@@ -95,6 +95,8 @@ def load_library() -> ctypes.CDLL:
     lib.ut_set_backbone_lanes.argtypes = [vp, i32]
     lib.ut_set_latency_mode.restype = i32
     lib.ut_set_latency_mode.argtypes = [vp, i32]
+    lib.ut_set_conv_arithmetic.restype = i32
+    lib.ut_set_conv_arithmetic.argtypes = [vp, i32]
     lib.ut_poll_status.restype = i32
     lib.ut_poll_status.argtypes = [vp, vp]
     _lib = lib
@@ -367,6 +369,12 @@ class HipEngine:
         """Few-crop launches split K across workgroups (per-frame tracking); results then agree with the default mode to
         fp32 rounding instead of bit for bit.  Off by default."""
         self._check(self.lib.ut_set_latency_mode(self._h, int(bool(on))), "ut_set_latency_mode")
+
+    def set_conv_arithmetic(self, mode: str):
+        """"fp32": exact fp32 matrix instructions (default).  "split_bf16": the batched backbone convolutions run on the bf16
+        matrix cores from exact three-way splits of both operands (fp32-level error, not the fp32 chain's bits);
+        "split_bf16_always": also the launches too small to fill the chip (tests)."""
+        self._check(self.lib.ut_set_conv_arithmetic(self._h, {"fp32": 0, "split_bf16": 1, "split_bf16_always": 2}[mode]), "ut_set_conv_arithmetic")
 
     def poll_status(self):
         self._check(self.lib.ut_poll_status(self._h, _stream(self.device)), "ut_poll_status")

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   if ((grid & 7) == 0) slot = (blockIdx.x & 7) * (grid >> 3) + (blockIdx.x >> 3);
 
   // ---- fetch side: the pixel stream runs three chunks ahead of the MFMAs, the weight stream two
-  int fa_tile = slot, fa_c = 0, fa_tap = 0, fa_chb = 0;      // pixel stream: tile, chunk, tap, channel-slice base
+  int fa_tile = slot, fa_tap = 0, fa_chb = 0;      // pixel stream: tile, tap, channel-slice base
   unsigned fa_stage = 0;                                      // byte offset of the ring stage it writes next
   int a_pix[AP], a_iy[AP], a_ix[AP];
   int fw_tile = slot, fw_c = 0;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
       a_ix[i] = ox * p.stride - p.pad;                                                               \
       a_pix[i] = ((img * p.H + a_iy[i]) * p.W + a_ix[i]) * p.cin + 4 * gk;                           \
     }                                                                                                \
-    fa_c = 0; fa_tap = 0; fa_chb = 0;                                                                \
+    fa_tap = 0; fa_chb = 0;                                                                \
   }
 #define SP_W_SETUP()                                                                                 \
   {                                                                                                  \
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
 #define SP_A_ADVANCE()                                                                               \
   {                                                                                                  \
     fa_stage = fa_stage + A_STAGE == A_RING * A_STAGE ? 0u : fa_stage + A_STAGE;                     \
-    ++fa_c; ++fa_tap;                                                                                \
+    ++fa_tap;                                                                                \
     if (fa_tap >= taps) { fa_tap = 0; fa_chb += 32; }                                                \
   }
   // weight block T of this wave: block q = wave * WP + T of the chunk image; group q / 6 of the tile column

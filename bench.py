@@ -48,6 +48,9 @@ def main():
                     help="backbone lanes: 2 = two half-batches on two internal streams (ut_set_backbone_lanes; +0.3 %%, "
                          "but concurrent launches make per-kernel durations in a rocprof trace overlap, so the default "
                          "keeps one lane and the trace comparable with the roofline leg)")
+    ap.add_argument("--conv", choices=["fp32", "split_bf16"], default="fp32",
+                    help="arithmetic of the batched backbone convolutions (ut_set_conv_arithmetic): exact fp32 matrix "
+                         "instructions, or exact 3-way bf16 splits of both operands on the bf16 matrix cores (fp32-level error)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend for N>1 (nccl = RCCL over xGMI; gloo only to rehearse the multi-process "
                          "control flow on a box with fewer GPUs than ranks: ranks then share devices)")
@@ -86,6 +89,7 @@ def main():
     if args.chunk:
         eng.set_backbone_chunk(args.chunk)
     eng.set_backbone_lanes(args.lanes)
+    eng.set_conv_arithmetic(args.conv)
 
     f_local = args.frames_per_gpu
     lo, hi = pipeline.shard_frames(f_local * world, rank, world)
@@ -141,6 +145,21 @@ def main():
     total_hf = s_local * world * args.steps
     value = total_hf / dt
     flops_hf = arch.FLOPS_PER_HANDFRAME_KNOWN if known else arch.FLOPS_PER_HANDFRAME_UNKNOWN
+
+    # split-bf16 mode: the records of the timed workload against the fp32-MFMA mode's on the same batch (checker leg)
+    split_check = None
+    if args.conv != "fp32" and rank == 0:
+        rec_split = hot.step(batch).clone()
+        eng.set_conv_arithmetic("fp32")
+        rec_fp32 = hot.step(batch).clone()
+        eng.set_conv_arithmetic(args.conv)
+        hot.check()
+        split_check = {"against": "the same step with UT_CONV_FP32 (itself pinned to the oracle by tests/ and parity_recording_00)",
+                       "hand_frames": int(rec_split.shape[0]),
+                       "max_joint_angle_diff_rad": float((rec_split[:, :22] - rec_fp32[:, :22]).abs().max()),
+                       "max_keypoint_diff_mm": float((rec_split[:, 60:] - rec_fp32[:, 60:]).reshape(rec_split.shape[0], -1, 3)
+                                                     .norm(dim=-1).max()),
+                       "tolerance": "BASELINE.json north_star: 1e-4 rad / 1e-3 mm"}
 
     roofline = None
     if not args.no_roofline:
@@ -204,6 +223,7 @@ def main():
                        "crops_per_step": n_local * world, "src_image": "480x636 u8 x 4 cameras",
                        "parallelism": f"frame-shard x{world}" + ("" if args.backend == "nccl" else " (gloo rehearsal)"),
                        "outputs_finite": finite},
+            "conv_arithmetic": args.conv, "split_bf16_check": split_check,
             "roofline": roofline, "cpu_baseline": cpu,
             "mpjpe_delta_mm": None if parity is None else parity["mpjpe_delta_mm"], "parity_recording_00": parity,
         }

@@ -81,6 +81,17 @@ int ut_poll_status(ut_handle h, void* stream);
  * are bit-identical.  Not applied between ut_profile_begin / ut_profile_end. */
 int ut_set_backbone_lanes(ut_handle h, int lanes);
 
+/* Arithmetic of the batched backbone convolutions (cin % 32 == 0, >= 64 channels out, launches that fill the chip).
+ *  UT_CONV_FP32        v_mfma_f32_32x32x2_f32: the exact fp32 multiply-add chain (default).
+ *  UT_CONV_SPLIT_BF16  both operands split exactly into three bf16 pieces (8 + 8 + 8 significand bits), six piece
+ *                      products per k on v_mfma_f32_32x32x16_bf16, fp32 accumulation: the terms dropped are below
+ *                      2^-24 of a product, so the result carries fp32-level rounding error (not the fp32 chain's bits:
+ *                      outputs agree with UT_CONV_FP32 to ~1e-6 relative) at up to 2.67x the matrix rate.
+ *  UT_CONV_SPLIT_BF16_ALWAYS  the same kernel also for launches too small to fill the chip (slower there: for tests).
+ * Every other launch (stem, layer1, 1x1 shortcuts, head, and all launches in latency mode) is unaffected. */
+enum { UT_CONV_FP32 = 0, UT_CONV_SPLIT_BF16 = 1, UT_CONV_SPLIT_BF16_ALWAYS = 2 };
+int ut_set_conv_arithmetic(ut_handle h, int mode);
+
 /* Latency mode for calls on a handful of crops (the per-frame tracker): convolutions whose launch has far fewer tiles
  * than the chip has CUs split K across workgroups and add the partial sums in a fixed order.  Deterministic, but not
  * the unsplit kernel's summation order: results agree with the default mode to fp32 rounding (~1e-6 relative), not

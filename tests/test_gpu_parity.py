@@ -80,6 +80,56 @@ def test_backbone_edge_batches(engine):
         engine.backbone(torch.zeros(2, 64, 64, device=DEV))
 
 
+@pytest.fixture(scope="module")
+def split_engine():
+    """The same weights with the eligible backbone convolutions on the split-bf16 kernel (conv_split.hip) for EVERY launch
+    size, so that the small parity cases below go through it."""
+    eng = _native.HipEngine(synth.synthetic_state_dict(0), DEV)
+    eng.set_conv_arithmetic("split_bf16_always")
+    yield eng
+    eng.close()
+
+
+def test_split_bf16_backbone_matches_oracle(engine, split_engine):
+    """conv_split.hip (bf16 matrix cores, exact 3-way operand splits, 6 products) against the fp32 oracle at the fp32
+    kernels' tolerance, on a ragged launch (7 crops: 1008 pixels at 12x12 = three full 256-row tiles and one of 240; 252
+    pixels at 6x6 = one partial tile in two column tiles) - and its distance to the fp32-MFMA mode."""
+    crops = synth.synthetic_crops(7, seed=3)
+    want = ref_model.backbone(ref_model.to_torch_state_dict(synth.synthetic_state_dict(0)), torch.from_numpy(crops))
+    got = split_engine.backbone(_dev(crops)).cpu()
+    scale = max(1.0, want.abs().max().item())
+    assert (got - want).abs().max().item() < 2e-5 * scale
+    fp32 = engine.backbone(_dev(crops)).cpu()
+    assert not torch.equal(got, fp32)                       # a different kernel did run
+    assert (got - fp32).abs().max().item() < 1e-5 * scale
+    assert torch.equal(split_engine.backbone(_dev(crops)).cpu(), got)       # deterministic
+
+
+def test_split_bf16_large_batch(engine):
+    """The default split mode engages on launches that fill the chip: 2048 + 37 crops (ragged last tiles at every
+    resolution), against the fp32-MFMA mode on the same crops and the oracle on a few of them."""
+    n = 2048 + 37
+    g = torch.Generator(device=DEV)
+    g.manual_seed(12)
+    crops = torch.rand(n, 96, 96, device=DEV, generator=g)
+    fp32 = engine.backbone(crops)
+    eng = _native.HipEngine(synth.synthetic_state_dict(0), DEV)
+    try:
+        eng.set_conv_arithmetic("split_bf16")
+        got = eng.backbone(crops)
+        assert torch.equal(eng.backbone(crops), got)
+        few = eng.backbone(crops[:5])                       # too few tiles: the fp32 kernels, bit for bit
+        assert torch.equal(few, engine.backbone(crops[:5]))
+    finally:
+        eng.close()
+    scale = max(1.0, fp32.abs().max().item())
+    assert not torch.equal(got, fp32)
+    assert (got - fp32).abs().max().item() < 1e-5 * scale
+    idx = [0, 1, 1000, 2047, n - 1]
+    want = ref_model.backbone(ref_model.to_torch_state_dict(synth.synthetic_state_dict(0)), crops[idx].cpu())
+    assert (got[idx].cpu() - want).abs().max().item() < 2e-5 * scale
+
+
 def _run_steps(engine, known, want_raw=True):
     engine.reset_memory()
     axes, rest = scenarios.skeleton_m()
@@ -96,6 +146,12 @@ def _run_steps(engine, known, want_raw=True):
         mem, ext = engine.get_memory()
         outs.append((feat.cpu().numpy(), pose.cpu().numpy(), raw.cpu().numpy(), mem.cpu().numpy(), ext.cpu().numpy()))
     return outs
+
+
+@pytest.mark.parametrize("known", [True, False])
+def test_split_bf16_model_matches_reference_goldens(split_engine, golden_dir, known):
+    """The reference's own outputs (tests/golden/model_*.npz), same tolerances, with the backbone on the split-bf16 kernel."""
+    test_model_matches_reference_goldens(split_engine, golden_dir, known)
 
 
 @pytest.mark.parametrize("known", [True, False])

@@ -16,11 +16,43 @@ CSRC = os.path.join(ROOT, "absolutetrack_amd", "csrc")
 cin, cout, hw, n_img = (int(a) for a in sys.argv[1:5])
 ksize = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 stride = int(sys.argv[6]) if len(sys.argv) > 6 else 1
-so = "/tmp/libsplitab.so"
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w", "-o", so,
-                       os.path.join(CSRC, "conv_igemm.hip"), os.path.join(CSRC, "conv_patch.hip"), os.path.join(CSRC, "conv_split.hip"),
-                       os.path.join(ROOT, "tools", "diag", "split_entry.hip"), "-I", CSRC])
-lib = ctypes.CDLL(so)
+# variants of conv_split.hip (text patches of a copy, see VARIANTS) are timed beside the product kernel: name,name,...
+VARIANTS = {
+    # no fp32 -> bf16 conversion work (wrong numbers): what the VALU split costs
+    "noconv": [("  const float ra = a - ", "  hi = ua; mid = ub; lo = ua; return;\n  const float ra = a - ")],
+    # no transfers after the prologue (stale operands): what the fetch costs
+    "nodma": [("#define SP_A_ISSUE(I, OFF) dma_piece(", "#define SP_A_ISSUE(I, OFF) if (p.k_pad < 0) dma_piece("),
+              ("    if (WTOT % 8 == 0 || q_ < WTOT) {", "    if (p.k_pad < 0) {")],
+    # no residual loads and no stores
+    "noepi": [("            __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, off, 0, 0);", "            if (p.k_pad < 0) __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, off, 0, 0);"),
+              ("            rr[g4] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0);", "            rr[g4] = u32x4{0, 0, 0, 0};")],
+}
+variants = [v for v in os.environ.get("SPLIT_VARIANTS", "").split(",") if v]
+
+
+def build(name, patches):
+    src = os.path.join(CSRC, "conv_split.hip")
+    if patches:
+        text = open(src).read()
+        for old, new in patches:
+            assert old in text, old
+            text = text.replace(old, new)
+        src = f"/tmp/conv_split_{name}.hip"
+        open(src, "w").write(text)
+    so = f"/tmp/libsplitab_{name}.so"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w", "-o", so,
+                           os.path.join(CSRC, "conv_igemm.hip"), os.path.join(CSRC, "conv_patch.hip"), src,
+                           os.path.join(ROOT, "tools", "diag", "split_entry.hip"), "-I", CSRC])
+    return ctypes.CDLL(so)
+
+
+lib = build("product", [])
+vlibs = {}
+for v in variants:
+    patches = []
+    for part in v.split("+"):
+        patches += VARIANTS[part]
+    vlibs[v] = build(v, patches)
 dev = "cuda:0"
 torch.manual_seed(0)
 ho = (hw + 2 * (ksize // 2) - ksize) // stride + 1
@@ -41,7 +73,7 @@ s_d = torch.from_numpy(split.view(np.int16)).to(dev)
 out = torch.empty(n_img, ho, ho, cout, device=dev)
 
 
-def run(mode):
+def run(mode, lib=lib):
     rc = lib.conv_diag2(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(w_d.data_ptr()), ctypes.c_void_p(s_d.data_ptr()),
                         ctypes.c_void_p(b_d.data_ptr()), ctypes.c_void_p(res.data_ptr()), ctypes.c_void_p(out.data_ptr()),
                         n_img, hw, cin, cout, ksize, stride, 1, mode)
@@ -63,17 +95,18 @@ for mode, name in ((0, "fp32 mfma"), (1, "split bf16x6")):
 a, b = outs["fp32 mfma"], outs["split bf16x6"]
 print(f"max |split - fp32| over all {n_img} images = {float((a - b).abs().max()):.3e}   (|out| max {float(a.abs().max()):.2f})")
 flops = 2.0 * n_img * ho * ho * cout * k_total
-times = {0: [], 1: []}
+cases = [("fp32 mfma", 0, lib), ("split bf16x6", 1, lib)] + [(v, 1, l) for v, l in vlibs.items()]
+times = {name: [] for name, _m, _l in cases}
 for rnd in range(10):
-    for mode in (0, 1):
+    for name, mode, l in cases:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(4):
-            run(mode)
+            run(mode, l)
         e1.record()
         torch.cuda.synchronize()
-        times[mode].append(e0.elapsed_time(e1) / 4)
-for mode, name in ((0, "fp32 mfma"), (1, "split bf16x6")):
-    t = times[mode]
+        times[name].append(e0.elapsed_time(e1) / 4)
+for name, _m, _l in cases:
+    t = times[name]
     med, mn = statistics.median(t), min(t)
     print(f"{name:14s} median {med*1e3:8.1f} us ({flops/med/1e9:6.1f} TF-equivalent)   min {mn*1e3:8.1f} us ({flops/mn/1e9:6.1f})")
