@@ -39,6 +39,11 @@ constexpr unsigned OOB = 0xFFFFFF00u;
 
 // LDS-DMA piece (see conv_igemm.hip::dma16): per-lane byte offset + wave-uniform byte offset
 __device__ __forceinline__ void dma_piece(u32x4 rsrc, unsigned lds_addr, unsigned voffset, unsigned soffset) {
+#ifdef SP_M0_NORESTORE
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+               :: "v"(voffset), "s"(lds_addr), "s"(rsrc), "s"(soffset) : "memory");
+  return;
+#endif
   unsigned keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
@@ -92,10 +97,37 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   constexpr int SLOT = W_BASE + W_RING * W_STAGE;
   constexpr int NM = 6 * MI * NI;          // MFMAs per k-step
   constexpr int UNITS = MI * 4;            // pair conversions per k-step
-  constexpr int CSTEP = (NM - 6) / UNITS;  // one every CSTEP MFMAs, from slot 4
+  constexpr int CSTEP = NM == 24 ? 2 : 1;  // one every CSTEP MFMAs
   static_assert(CSTEP >= 1, "room for the conversions");
-  constexpr int ASL = 4 + WP + 2 * AP <= NM ? 2 : 1;   // MFMA slots per pixel piece (offset and transfer apart if there is room)
-  static_assert(4 + WP + ASL * AP <= NM, "room for the transfers");
+#ifndef SP_WF_SPREAD
+#define SP_WF_SPREAD 1
+#endif
+#ifndef SP_BAR24
+#define SP_BAR24 18
+#endif
+#ifndef SP_CONV0
+#define SP_CONV0 4
+#endif
+  constexpr bool WFS = SP_WF_SPREAD;       // weight fragment reads one per WSP slots from slot 2 instead of all at the step's start
+#ifndef SP_SPLIT_BARRIER
+#define SP_SPLIT_BARRIER 1
+#endif
+  // The chunk barrier in two halves through an LDS counter: a wave ARRIVES (its reads of the chunk are done, its pieces of
+  // the next chunk have landed) well before it WAITS for the others (in front of its first transfer into the freed
+  // buffers), so that the one workgroup of the CU does not idle through the barrier's turn-around every chunk.
+  constexpr bool SPB = SP_SPLIT_BARRIER;
+  constexpr int WSP1 = (SPB || NM != 24) ? 1 : 3;   // spacing of the weight-fragment reads in the chunk's first k-step
+  constexpr int WSP2 = NM == 24 ? 3 : 1;            // ... in its second k-step
+  constexpr int ARR = 2 + WSP1 * (NI * 3 - 1) + (NM == 24 ? 3 : 2);  // slot of the arrival: behind the last fragment read
+  constexpr int BAR = NM == 24 ? SP_BAR24 : (SPB ? ARR + 1 : WFS ? 2 + WSP1 * (NI * 3 - 1) + 1 : NM / 2 - 1);
+  constexpr int CV0 = NM == 24 ? SP_CONV0 : 4;   // slot of the first conversion unit
+  static_assert(!WFS || BAR > 2 + WSP1 * (NI * 3 - 1), "the barrier follows the chunk's last fragment read");
+  static_assert(!SPB || (WFS && ARR < BAR && ARR < NM), "arrival before the wait, both in the first k-step");       // MFMA slot of the first k-step that carries the chunk barrier; the transfers follow it
+#ifndef SP_PSTEP24
+#define SP_PSTEP24 ((2 * NM - BAR - 3) / (WP + AP - 1))
+#endif
+  constexpr int PSTEP = NM == 24 ? SP_PSTEP24 : (2 * NM - BAR - 3) / (WP + AP - 1);   // MFMA slots between two transfers of a wave
+  static_assert(PSTEP >= 2 && BAR + 2 + (WP + AP - 1) * PSTEP < 2 * NM, "room for the transfers");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -207,16 +239,22 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
     for (int h = 0; h < 2; ++h) x_pos[s][h] = (unsigned)(((4 * s + 2 * fh + h) ^ ((fr >> 1) & 7)) * 16);
   const unsigned w_rd = (unsigned)(W_BASE + wn * NI * 6 * 1024) + w_lane;
 
-#define SP_READ(SET, S, A_ST, W_ST)                                                                  \
+#define SP_READ_W1(SET, S, IDX)                                                                      \
+  {                                                                                                  \
+    constexpr int j_ = (IDX) / 3, pl_ = (IDX) % 3;                                                   \
+    const u32x4 t_ = *reinterpret_cast<const u32x4*>(smem + w_rd + rd_w + ((j_ * 2 + (S)) * 3 + pl_) * 1024); \
+    wf[SET][j_][pl_][0] = t_.x; wf[SET][j_][pl_][1] = t_.y; wf[SET][j_][pl_][2] = t_.z; wf[SET][j_][pl_][3] = t_.w; \
+  }
+#define SP_READ_X(S, A_ST)                                                                           \
   {                                                                                                  \
     _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
       _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                  \
         xr[i][h] = *reinterpret_cast<const float4*>(smem + (A_ST) + x_row + i * 4096 + x_pos[S][h]); \
-    _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                   \
-      _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                                             \
-        const u32x4 t_ = *reinterpret_cast<const u32x4*>(smem + w_rd + (W_ST) + ((j * 2 + (S)) * 3 + pl) * 1024); \
-        wf[SET][j][pl][0] = t_.x; wf[SET][j][pl][1] = t_.y; wf[SET][j][pl][2] = t_.z; wf[SET][j][pl][3] = t_.w; \
-      }                                                                                              \
+  }
+#define SP_READ_WALL(SET, S)                                                                         \
+  {                                                                                                  \
+    SP_READ_W1(SET, S, 0) SP_READ_W1(SET, S, 1) SP_READ_W1(SET, S, 2)                                \
+    SP_READ_W1(SET, S, 3) SP_READ_W1(SET, S, 4) SP_READ_W1(SET, S, 5)                                \
   }
   // conversion unit U of a k-step: pair (U & 3) of row fragment U >> 2
 #define SP_CONV(SET, U)                                                                              \
@@ -240,22 +278,40 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   // RA / RW, k-step RS of that chunk).  FIRST: the chunk's first step, which carries the barrier and the transfers.
 #define SP_SLOT(CUR, NXT, N, FIRST)                                                                  \
   {                                                                                                  \
-    if constexpr (FIRST && (N) == 3) {                                                               \
+    if constexpr (FIRST && (N) == (SPB ? ARR : BAR)) {                                               \
       if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    \
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP) : "memory");                                 \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
-      __builtin_amdgcn_s_barrier();                                                                  \
       drain = false;                                                                                 \
+      if constexpr (SPB) {                                                                           \
+        unsigned long long keep_;                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0" \
+                     : "=&s"(keep_) : "v"(bar_addr), "v"(1u) : "memory");                            \
+      }                                                                                              \
+    }                                                                                                \
+    if constexpr (FIRST && (N) == BAR) {                                                             \
+      if constexpr (SPB) {                                                                           \
+        bar_target += 8u;                                                                            \
+        for (;;) {                                                                                   \
+          unsigned seen_;                                                                            \
+          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen_) : "v"(bar_addr) : "memory"); \
+          if ((int)(__builtin_amdgcn_readfirstlane(seen_) - bar_target) >= 0) break;                 \
+        }                                                                                            \
+      } else {                                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
+        __builtin_amdgcn_s_barrier();                                                                \
+      }                                                                                              \
       /* the ticket taken at the tile's start is older than every transfer still in flight here */    \
       if (c == 1 && tid == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(slot_addr), "v"(grid + ticket) : "memory"); \
     }                                                                                                \
-    if constexpr (FIRST && (N) >= 4 && (N) < 4 + WP) SP_W_ISSUE((N) - 4);                            \
-    if constexpr (FIRST && (N) >= 4 + WP && (N) < 4 + WP + ASL * AP) {                               \
-      constexpr int k_ = (N) - 4 - WP;                                                               \
-      if constexpr (ASL == 1) { SP_A_ADDR(k_, a_off); SP_A_ISSUE(k_, a_off); }                       \
-      else if constexpr ((k_ & 1) == 0) { SP_A_ADDR(k_ >> 1, a_off); } else { SP_A_ISSUE(k_ >> 1, a_off); } \
-    }                                                                                                \
-    if constexpr ((N) >= 4 && ((N) - 4) % CSTEP == 0 && ((N) - 4) / CSTEP < UNITS) SP_CONV(NXT, ((N) - 4) / CSTEP); \
+    /* transfers: piece k of the wave (weights first) at chunk slot BAR + 1 + k * PSTEP, spread over the rest of the \
+       chunk - the CU's one vector-memory pipe takes 16 cycles per piece, 8 waves x 7 pieces per chunk */ \
+    constexpr int g_ = (FIRST ? 0 : NM) + (N) - BAR - 1;                                             \
+    if constexpr (g_ >= 0 && g_ % PSTEP == 0 && g_ / PSTEP < WP) SP_W_ISSUE(g_ / PSTEP);              \
+    if constexpr (g_ >= 0 && g_ % PSTEP == 0 && g_ / PSTEP >= WP && g_ / PSTEP < WP + AP) SP_A_ADDR(g_ / PSTEP - WP, a_off); \
+    if constexpr (g_ >= 1 && (g_ - 1) % PSTEP == 0 && (g_ - 1) / PSTEP >= WP && (g_ - 1) / PSTEP < WP + AP) SP_A_ISSUE((g_ - 1) / PSTEP - WP, a_off); \
+    if constexpr ((N) >= CV0 && ((N) - CV0) % CSTEP == 0 && ((N) - CV0) / CSTEP < UNITS) SP_CONV(NXT, ((N) - CV0) / CSTEP); \
+    constexpr int wsp_ = FIRST ? WSP1 : WSP2;                                                        \
+    if constexpr (WFS && (N) >= 2 && ((N) - 2) % wsp_ == 0 && ((N) - 2) / wsp_ < NI * 3) SP_READ_W1(NXT, FIRST ? 1 : 0, ((N) - 2) / wsp_); \
     SP_PIN();                                                                                        \
     SP_MFMA(CUR, N);                                                                                 \
     SP_PIN();                                                                                        \
@@ -268,6 +324,9 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   }
 
   const unsigned slot_addr = smem_addr + (unsigned)SLOT;
+  const unsigned bar_addr = slot_addr + 4;     // arrivals of the split chunk barrier (monotonic)
+  unsigned bar_target = 0;
+  if (tid == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(bar_addr), "v"(0u) : "memory");
   // ---- prologue: chunks 0 and 1 of the first tile and the pixels of chunk 2
   SP_A_SETUP();
   SP_W_SETUP();
@@ -293,7 +352,8 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
     for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  SP_READ(0, 0, 0u, 0u);
+  SP_READ_X(0, 0u);
+  SP_READ_WALL(0, 0);
   SP_CONV(0, 0) SP_CONV(0, 1) SP_CONV(0, 2) SP_CONV(0, 3)
   if constexpr (UNITS > 4) { SP_CONV(0, 4) SP_CONV(0, 5) SP_CONV(0, 6) SP_CONV(0, 7) }
 
@@ -313,15 +373,17 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
       if (c == n_chunks - 2) { fw_tile = next_tile; SP_W_SETUP(); }
       SP_A_TAP();
       // first k-step: set 0; its slot 0 reads the second k-step of the same chunk into set 1
-      SP_READ(1, 1, rd_a, rd_w);
+      SP_READ_X(1, rd_a);
+      if constexpr (!WFS) SP_READ_WALL(1, 1);
       SP_STEP(0, 1, true)
-      SP_A_ADVANCE();
-      SP_W_ADVANCE();
       // second k-step: set 1; reads the first k-step of the next chunk (published by this chunk's barrier) into set 0
       rd_a = rd_a + A_STAGE == A_RING * A_STAGE ? 0u : rd_a + A_STAGE;
       rd_w ^= W_STAGE;
-      SP_READ(0, 0, rd_a, rd_w);
+      SP_READ_X(0, rd_a);
+      if constexpr (!WFS) SP_READ_WALL(0, 0);
       SP_STEP(1, 0, false)
+      SP_A_ADVANCE();
+      SP_W_ADVANCE();
     }
     // ---- epilogue: bias + residual + ReLU + store
     {
@@ -371,7 +433,9 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
 #undef SP_A_ADVANCE
 #undef SP_W_ISSUE
 #undef SP_W_ADVANCE
-#undef SP_READ
+#undef SP_READ_X
+#undef SP_READ_WALL
+#undef SP_READ_W1
 #undef SP_CONV
 #undef SP_PIN
 #undef SP_MFMA

@@ -23,10 +23,10 @@ from absolutetrack_amd import pipeline, synth
 from oracle import checks, ref_model
 
 
-def _split(x: torch.Tensor, n: int):
+def _split(x: torch.Tensor, n: int, dtype=torch.bfloat16):
     parts, r = [], x
     for _ in range(n):
-        p = r.bfloat16().float()
+        p = r.to(dtype).float()
         parts.append(p)
         r = r - p
     return parts
@@ -44,6 +44,19 @@ class _SplitF:
     def conv2d(self, x, w, bias=None, stride=1, padding=0, *a, **k):
         if self.products == 0 or x.shape[1] < 32:
             return F.conv2d(x, w, bias, stride, padding, *a, **k)
+        if self.products in (-3, -4):
+            # fp16 pieces (11 significand bits each, two per operand): x0 w0 + x0 w1 + x1 w0 (+ x1 w1); the weights are
+            # pre-scaled by a power of two so that their second piece stays a normal fp16 number, the activations are not
+            sc = 2.0 ** (14 - int(torch.ceil(torch.log2(w.abs().max()))))
+            xs, ws = _split(x, 2, torch.float16), _split(w * sc, 2, torch.float16)
+            assert all(torch.isfinite(t).all() for t in xs + ws)
+            pairs = [(1, 1)] * (self.products == -4) + [(0, 1), (1, 0), (0, 0)]
+            y = None
+            for i, j in pairs:
+                t = F.conv2d(xs[i], ws[j], None, stride, padding, *a, **k)
+                y = t if y is None else y + t
+            y = y * (1.0 / sc)
+            return y if bias is None else y + bias.view(1, -1, 1, 1)
         n = {1: 1, 3: 2, 6: 3}[self.products]
         xs, ws = _split(x, n), _split(w, n)
         pairs = {1: [(0, 0)], 3: [(0, 0), (0, 1), (1, 0)], 6: [(0, 0), (0, 1), (1, 0), (1, 1), (0, 2), (2, 0)]}[self.products]
@@ -62,7 +75,7 @@ def run(n_frames: int, known: bool):
     frames = rng.integers(0, 256, (n_frames, 4, 480, 636), dtype=np.uint8)
     out = {}
     base = None
-    for products in (0, 1, 3, 6):
+    for products in (0, 1, 3, 6, -3, -4):
         ref_model.F = _SplitF(products)
         try:
             o = checks.oracle_frames(sd, lab, hm_np, range(n_frames), frames, known=known)
@@ -71,7 +84,7 @@ def run(n_frames: int, known: bool):
         if base is None:
             base = o
             continue
-        out[f"bf16x{products}"] = {
+        out[f"bf16x{products}" if products > 0 else f"fp16x{-products}"] = {
             "max_abs_joint_angle_rad": float(np.abs(o["joint_angles"] - base["joint_angles"]).max()),
             "max_abs_wrist_xf": float(np.abs(o["wrist_xfs"] - base["wrist_xfs"]).max()),
             "max_keypoint_mm": float(np.linalg.norm(o["keypoints_mm"] - base["keypoints_mm"], axis=-1).max()),

@@ -23,6 +23,11 @@ VARIANTS = {
     # no transfers after the prologue (stale operands): what the fetch costs
     "nodma": [("#define SP_A_ISSUE(I, OFF) dma_piece(", "#define SP_A_ISSUE(I, OFF) if (p.k_pad < 0) dma_piece("),
               ("    if (WTOT % 8 == 0 || q_ < WTOT) {", "    if (p.k_pad < 0) {")],
+    # transfers issued but out of range (zeros land, nothing is fetched): issue cost without the data path
+    "oobdma": [("    OFF = ok ? (unsigned)(a_pix[I] + f_tap_off) * 4u : OOB; ", "    OFF = p.k_pad < 0 ? (unsigned)(a_pix[I] + f_tap_off) * 4u : OOB + (ok ? 0u : 16u); "),
+               ("(unsigned)q_ * 1024u, w_lane, src_);", "(unsigned)q_ * 1024u, OOB, src_);")],
+    # no chunk barrier (only meaningful together with nodma)
+    "nobar": [("      __builtin_amdgcn_s_barrier();  ", "      if (p.k_pad < 0) __builtin_amdgcn_s_barrier();  ")],
     # no residual loads and no stores
     "noepi": [("            __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, off, 0, 0);", "            if (p.k_pad < 0) __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, off, 0, 0);"),
               ("            rr[g4] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0);", "            rr[g4] = u32x4{0, 0, 0, 0};")],
@@ -30,7 +35,7 @@ VARIANTS = {
 variants = [v for v in os.environ.get("SPLIT_VARIANTS", "").split(",") if v]
 
 
-def build(name, patches):
+def build(name, patches, flags=()):
     src = os.path.join(CSRC, "conv_split.hip")
     if patches:
         text = open(src).read()
@@ -40,7 +45,7 @@ def build(name, patches):
         src = f"/tmp/conv_split_{name}.hip"
         open(src, "w").write(text)
     so = f"/tmp/libsplitab_{name}.so"
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w", "-o", so,
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w", *flags, "-o", so,
                            os.path.join(CSRC, "conv_igemm.hip"), os.path.join(CSRC, "conv_patch.hip"), src,
                            os.path.join(ROOT, "tools", "diag", "split_entry.hip"), "-I", CSRC])
     return ctypes.CDLL(so)
@@ -49,10 +54,13 @@ def build(name, patches):
 lib = build("product", [])
 vlibs = {}
 for v in variants:
-    patches = []
+    patches, flags = [], []
     for part in v.split("+"):
-        patches += VARIANTS[part]
-    vlibs[v] = build(v, patches)
+        if part.startswith("-D"):
+            flags.append(part)
+        else:
+            patches += VARIANTS[part]
+    vlibs[v] = build(v.replace("=", "_"), patches, flags)
 dev = "cuda:0"
 torch.manual_seed(0)
 ho = (hw + 2 * (ksize // 2) - ksize) // stride + 1
