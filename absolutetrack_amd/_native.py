@@ -371,10 +371,10 @@ class HipEngine:
         self._check(self.lib.ut_set_latency_mode(self._h, int(bool(on))), "ut_set_latency_mode")
 
     def set_conv_arithmetic(self, mode: str):
-        """"fp32": exact fp32 matrix instructions (default).  "split_bf16": the batched backbone convolutions run on the bf16
-        matrix cores from exact three-way splits of both operands (fp32-level error, not the fp32 chain's bits);
-        "split_bf16_always": also the launches too small to fill the chip (tests)."""
-        self._check(self.lib.ut_set_conv_arithmetic(self._h, {"fp32": 0, "split_bf16": 1, "split_bf16_always": 2}[mode]), "ut_set_conv_arithmetic")
+        """"fp32": exact fp32 matrix instructions (default).  "split_f16": the batched backbone convolutions run on the fp16
+        matrix cores from two-piece splits of both operands (fp32-level error, not the fp32 chain's bits);
+        "split_f16_always": also the launches too small to fill the chip (tests)."""
+        self._check(self.lib.ut_set_conv_arithmetic(self._h, {"fp32": 0, "split_f16": 1, "split_f16_always": 2}[mode]), "ut_set_conv_arithmetic")
 
     def poll_status(self):
         self._check(self.lib.ut_poll_status(self._h, _stream(self.device)), "ut_poll_status")

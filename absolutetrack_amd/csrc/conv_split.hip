@@ -1,28 +1,36 @@
-// Split-bf16 implicit-GEMM convolution for gfx950: fp32 results from the bf16 matrix cores.
+// Split-fp16 implicit-GEMM convolution for gfx950: fp32-level results from the fp16 matrix cores.
 //
-// An fp32 value is the exact sum of three bf16 pieces (8 + 8 + 8 significand bits: hi = the top half of the fp32 word,
-// mid = the top half of x - hi, lo = x - hi - mid), a product of two bf16 values is exact in fp32, and
-// v_mfma_f32_32x32x16_bf16 accumulates in fp32.  Six of the nine piece products,
-//     x0 w0 + x0 w1 + x1 w0 + x1 w1 + x0 w2 + x2 w0 ,
-// drop only terms below 2^-24 of the full product - the rounding error of one fp32 multiply - so a convolution built
-// from them carries fp32-level error (oracle/studies/split_precision.py: 2.4e-7 rad at the joint angles, the same as a
-// change of summation order) while the matrix pipe needs 6 x 32 cycles per 16 k instead of 16 x 64 / 2 = 512:
-// 2.67x the rate of v_mfma_f32_32x32x2_f32.  Same layers as conv_igemm.hip (lib/models/backbone_resnet.py:56-72),
-// same NHWC fp32 tensors in HBM; only the arithmetic inside the kernel changes.
+// An fp32 value x is split into two fp16 pieces, x0 = fp16(x) and x1 = fp16(x - x0) (x - x0 is exact in fp32): together
+// 22 significand bits, with an absolute floor of 2^-25 (half the fp16 subnormal quantum) for small values.  A product of
+// two fp16 values is exact in fp32 and v_mfma_f32_32x32x16_f16 accumulates in fp32, so
+//     x0 w0 + x0 w1 + x1 w0
+// drops only x1 w1 and the two rounding remainders: terms of ~2^-22 of a product, against the 2^-24 of one fp32 rounding.
+// At the path's outputs that is indistinguishable from a change of summation order (oracle/studies/split_precision.py:
+// 2.4e-7 rad at the joint angles, 2e-4 mm at the keypoints, the same as the six-product bf16 split and as the fp32 kernels
+// against the oracle), while the matrix pipe needs 3 x 32 cycles per 16 k instead of 16 x 64 / 2 = 512: 5.3x the rate
+// of v_mfma_f32_32x32x2_f32.  Same layers as conv_igemm.hip (lib/models/backbone_resnet.py:56-72), same NHWC fp32
+// tensors in HBM; only the arithmetic inside the kernel changes.
+// Range: an activation must stay below 65504 in magnitude (fp16's largest finite value; the first piece saturates there
+// and the second takes the rest up to 131008) - post-BatchNorm/ReLU activations of this network are O(1..100).  The
+// weights are pre-scaled per layer by a power of two that puts their largest magnitude just under 2^15, so that the
+// second weight piece of all but vanishing weights is a normal fp16 number; the epilogue multiplies by the inverse.
 //
-// Activations stay fp32 in HBM and in LDS and are split in registers after the fragment read (4 VALU per value + 3
-// v_perm per pair; the weights' pieces are made once on the host and stored as bf16 planes in fragment order, so a
-// wave reads a weight fragment with one conflict-free ds_read_b128 per (32 rows, 16 k, plane)).
+// Activations stay fp32 in HBM and in LDS and are split in registers after the fragment read (6 VALU per pair of
+// values: v_cvt_pkrtz_f16_f32, two conversions back, two subtractions, v_cvt_pkrtz_f16_f32); the weights' pieces are made
+// once on the host and stored as fp16 planes in fragment order, so a wave reads a weight fragment with one
+// conflict-free ds_read_b128 per (32 rows, 16 k, plane) - and they take the same 4 bytes per value as fp32.
 //
 // One workgroup of 8 waves per CU computes 256 x BN output tiles, K in chunks of 32 (two MFMA k-steps).  Operands go
-// global -> LDS by LDS-DMA into rings: 3 stages of pixels (im2col gather, XOR-swizzled 128-byte rows as in
-// conv_igemm.hip), 2 stages of weights (L2 resident, shorter latency).  One barrier per chunk, early in its first
-// k-step: at that point every fragment of the chunk is in registers, so the barrier both publishes the next chunk and
-// frees the current chunk's buffers, into which the transfers for two (weights) and three (pixels) chunks ahead are
-// issued right behind it; the wait in front of the barrier is a counted vmcnt that leaves the youngest pixel pieces in
-// flight.  Persistent grid with the same tile queue as conv_igemm.hip; the fetch side runs across tile boundaries.
-// Epilogue: bias + residual + ReLU + 16-byte NHWC stores (the accumulator layout of the 32x32 MFMAs is the same as in
-// conv_igemm.hip: a lane owns one pixel, register quads are 4 consecutive channels).
+// global -> LDS by LDS-DMA into rings of 3 stages (pixels: im2col gather, XOR-swizzled 128-byte rows as in
+// conv_igemm.hip).  One synchronisation per chunk, in two halves through an LDS counter: a wave ARRIVES once its
+// reads of the chunk are done and its pieces of the next chunk have landed (a counted vmcnt that leaves the youngest
+// pixel pieces in flight), and only WAITS for the other waves in front of its first transfer into the freed buffers.
+// The transfers of a chunk are spread over its MFMA slots (the CU's vector-memory pipe takes 16 cycles per 1-KB piece).
+// Persistent grid with the same tile queue as conv_igemm.hip; the fetch side runs across tile boundaries.
+// Epilogue: scale + bias + residual + ReLU + 16-byte NHWC stores (the accumulator layout of the 32x32 MFMAs is the same
+// as in conv_igemm.hip: a lane owns one pixel, register quads are 4 consecutive channels).
+#include <math.h>
+
 #include <atomic>
 
 #include "ut_kernels.h"
@@ -32,7 +40,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) char lds_char;
 
 constexpr unsigned OOB = 0xFFFFFF00u;
@@ -68,20 +77,17 @@ __device__ __forceinline__ int fdiv(int n, int d, float inv_d) {
   return q;
 }
 
-// two fp32 values -> their (hi, mid, lo) bf16 pieces, packed {second, first} per plane
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
-  const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
-  const float ra = a - __uint_as_float(ua & 0xFFFF0000u), rb = b - __uint_as_float(ub & 0xFFFF0000u);
-  const unsigned uar = __float_as_uint(ra), ubr = __float_as_uint(rb);
-  const float la = ra - __uint_as_float(uar & 0xFFFF0000u), lb = rb - __uint_as_float(ubr & 0xFFFF0000u);
-  hi = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
-  mid = __builtin_amdgcn_perm(ubr, uar, 0x07060302u);
-  lo = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), 0x07060302u);
+// two fp32 values -> their fp16 pieces (first, remainder), each packed {b, a}
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsigned& p1) {
+  const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
+  const float ra = a - (float)h[0], rb = b - (float)h[1];
+  p0 = __builtin_bit_cast(unsigned, h);
+  p1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
 }
-__device__ __forceinline__ bf16x8 frag(const unsigned (&v)[4]) {
+__device__ __forceinline__ f16x8 frag(const unsigned (&v)[4]) {
   u32x4 t;
   t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
-  return __builtin_bit_cast(bf16x8, t);
+  return __builtin_bit_cast(f16x8, t);
 }
 
 template <int BM, int BN, int WR, int WC>
@@ -89,45 +95,23 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   static_assert(WR * WC == 8, "8 waves per workgroup");
   constexpr int MI = BM / WR / 32, NI = BN / WC / 32;
   constexpr int AP = BM / 64;              // pixel pieces per wave per chunk (a piece = 8 rows x 128 B)
-  constexpr int WTOT = BN / 32 * 6;        // 1-KB weight blocks per chunk: (32 rows) x (k-step) x (plane)
+  constexpr int WTOT = BN / 32 * 4;        // 1-KB weight blocks per chunk: (32 rows) x (k-step) x (plane)
   constexpr int WP = (WTOT + 7) / 8;       // ... per wave
-  constexpr int A_STAGE = BM * 128, W_STAGE = BN * 192;
-  constexpr int A_RING = 3, W_RING = 2;
+  constexpr int A_STAGE = BM * 128, W_STAGE = BN * 128;
+  constexpr int A_RING = 3, W_RING = 3;
   constexpr int W_BASE = A_RING * A_STAGE;
   constexpr int SLOT = W_BASE + W_RING * W_STAGE;
-  constexpr int NM = 6 * MI * NI;          // MFMAs per k-step
-  constexpr int UNITS = MI * 4;            // pair conversions per k-step
-  constexpr int CSTEP = NM == 24 ? 2 : 1;  // one every CSTEP MFMAs
-  static_assert(CSTEP >= 1, "room for the conversions");
-#ifndef SP_WF_SPREAD
-#define SP_WF_SPREAD 1
-#endif
-#ifndef SP_BAR24
-#define SP_BAR24 18
-#endif
-#ifndef SP_CONV0
-#define SP_CONV0 4
-#endif
-  constexpr bool WFS = SP_WF_SPREAD;       // weight fragment reads one per WSP slots from slot 2 instead of all at the step's start
-#ifndef SP_SPLIT_BARRIER
-#define SP_SPLIT_BARRIER 1
-#endif
-  // The chunk barrier in two halves through an LDS counter: a wave ARRIVES (its reads of the chunk are done, its pieces of
-  // the next chunk have landed) well before it WAITS for the others (in front of its first transfer into the freed
-  // buffers), so that the one workgroup of the CU does not idle through the barrier's turn-around every chunk.
-  constexpr bool SPB = SP_SPLIT_BARRIER;
-  constexpr int WSP1 = (SPB || NM != 24) ? 1 : 3;   // spacing of the weight-fragment reads in the chunk's first k-step
-  constexpr int WSP2 = NM == 24 ? 3 : 1;            // ... in its second k-step
-  constexpr int ARR = 2 + WSP1 * (NI * 3 - 1) + (NM == 24 ? 3 : 2);  // slot of the arrival: behind the last fragment read
-  constexpr int BAR = NM == 24 ? SP_BAR24 : (SPB ? ARR + 1 : WFS ? 2 + WSP1 * (NI * 3 - 1) + 1 : NM / 2 - 1);
-  constexpr int CV0 = NM == 24 ? SP_CONV0 : 4;   // slot of the first conversion unit
-  static_assert(!WFS || BAR > 2 + WSP1 * (NI * 3 - 1), "the barrier follows the chunk's last fragment read");
-  static_assert(!SPB || (WFS && ARR < BAR && ARR < NM), "arrival before the wait, both in the first k-step");       // MFMA slot of the first k-step that carries the chunk barrier; the transfers follow it
-#ifndef SP_PSTEP24
-#define SP_PSTEP24 ((2 * NM - BAR - 3) / (WP + AP - 1))
-#endif
-  constexpr int PSTEP = NM == 24 ? SP_PSTEP24 : (2 * NM - BAR - 3) / (WP + AP - 1);   // MFMA slots between two transfers of a wave
-  static_assert(PSTEP >= 2 && BAR + 2 + (WP + AP - 1) * PSTEP < 2 * NM, "room for the transfers");
+  constexpr int NM = 3 * MI * NI;          // MFMAs (= slots) per k-step; a chunk has 2 * NM
+  constexpr int UNITS = MI * 4;            // pair conversions per k-step, one per slot from CV0
+  constexpr int NWF = NI * 2;              // weight-fragment reads per k-step, one per slot from RD0
+  constexpr int RD0 = NM >= 12 ? 2 : 0;
+  constexpr int CV0 = NM >= 12 ? 4 : 2;
+  constexpr int ARR = RD0 + NWF + (NM >= 12 ? 2 : 0);   // slot of the arrival: behind the chunk's last fragment read
+  constexpr int BAR = ARR + 1;                           // slot of the wait; the transfers follow it
+  constexpr int PSTEP = (2 * NM - BAR - 2) / (WP + AP);  // slots between two transfers of a wave
+  constexpr int ASEP = PSTEP >= 2 ? 1 : 0;               // a pixel piece's offset arithmetic one slot ahead of its transfer
+  static_assert(ARR < NM && BAR < NM && CV0 + UNITS <= NM, "arrival, wait and conversions inside the first k-step");
+  static_assert(PSTEP >= 1 && BAR + 1 + (WP + AP - 1) * PSTEP + ASEP < 2 * NM, "room for the transfers");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -153,7 +137,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   const __amdgpu_buffer_rsrc_t q_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.tile_counter, 0, 4, 0x00020000);
   const unsigned q_off = tid == 0 ? 0u : OOB;
   const u32x4 a_words = rsrc_words(p.in, (unsigned)((size_t)p.n_img * p.H * p.W * p.cin * sizeof(float)));
-  const u32x4 w_words = rsrc_words(p.w_split, (unsigned)((size_t)(p.cout_pad / 32) * n_chunks * 6144));
+  const u32x4 w_words = rsrc_words(p.w_split, (unsigned)((size_t)(p.cout_pad / 32) * n_chunks * 4096));
   const unsigned smem_addr = (unsigned)(unsigned long)(lds_char*)smem;
 
   const int grid = gridDim.x;
@@ -189,7 +173,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
 #define SP_W_SETUP()                                                                                 \
   {                                                                                                  \
     const int tn_ = fw_tile - (fw_tile / tiles_n) * tiles_n;                                         \
-    fw_row = (unsigned)(tn_ * (BN / 32)) * (unsigned)n_chunks * 6144u;                               \
+    fw_row = (unsigned)(tn_ * (BN / 32)) * (unsigned)n_chunks * 4096u;                               \
     fw_c = 0;                                                                                        \
   }
   // one pixel piece of the fetch chunk: per-lane offset, then the transfer
@@ -213,21 +197,19 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
     ++fa_tap;                                                                                \
     if (fa_tap >= taps) { fa_tap = 0; fa_chb += 32; }                                                \
   }
-  // weight block T of this wave: block q = wave * WP + T of the chunk image; group q / 6 of the tile column
+  // weight block T of this wave: block q = wave * WP + T of the chunk image; group q / 4 of the tile column
 #define SP_W_ISSUE(T)                                                                                \
   {                                                                                                  \
     const int q_ = wave * WP + (T);                                                                  \
-    if (WTOT % 8 == 0 || q_ < WTOT) {                                                                \
-      const unsigned src_ = fw_row + (unsigned)((q_ / 6) * n_chunks + fw_c) * 6144u + (unsigned)(q_ % 6) * 1024u; \
-      dma_piece(w_words, smem_addr + W_BASE + fw_stage + (unsigned)q_ * 1024u, w_lane, src_);        \
-    }                                                                                                \
+    const unsigned src_ = fw_row + (unsigned)((q_ / 4) * n_chunks + fw_c) * 4096u + (unsigned)(q_ % 4) * 1024u; \
+    dma_piece(w_words, smem_addr + W_BASE + fw_stage + (unsigned)q_ * 1024u, w_lane, src_);          \
   }
-#define SP_W_ADVANCE() { fw_stage ^= W_STAGE; ++fw_c; }
+#define SP_W_ADVANCE() { fw_stage = fw_stage + W_STAGE == W_RING * W_STAGE ? 0u : fw_stage + W_STAGE; ++fw_c; }
 
   // ---- compute side
   f32x16 acc[MI][NI];
-  unsigned xp[2][MI][3][4];      // pixel fragments, pieces (hi, mid, lo), two k-steps in flight
-  unsigned wf[2][NI][3][4];      // weight fragments
+  unsigned xp[2][MI][2][4];      // pixel fragments, pieces (first, remainder), two k-steps in flight
+  unsigned wf[2][NI][2][4];      // weight fragments
   float4 xr[MI][2];              // raw fp32 pixels of the k-step being converted
   unsigned rd_a = 0, rd_w = 0;   // ring stages being read
   // per-lane read offsets: pixel row fr of the wave's rows, 16-byte positions (4s + 2fh + h) ^ swizzle
@@ -237,12 +219,12 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int h = 0; h < 2; ++h) x_pos[s][h] = (unsigned)(((4 * s + 2 * fh + h) ^ ((fr >> 1) & 7)) * 16);
-  const unsigned w_rd = (unsigned)(W_BASE + wn * NI * 6 * 1024) + w_lane;
+  const unsigned w_rd = (unsigned)(W_BASE + wn * NI * 4 * 1024) + w_lane;
 
 #define SP_READ_W1(SET, S, IDX)                                                                      \
   {                                                                                                  \
-    constexpr int j_ = (IDX) / 3, pl_ = (IDX) % 3;                                                   \
-    const u32x4 t_ = *reinterpret_cast<const u32x4*>(smem + w_rd + rd_w + ((j_ * 2 + (S)) * 3 + pl_) * 1024); \
+    constexpr int j_ = (IDX) / 2, pl_ = (IDX) % 2;                                                   \
+    const u32x4 t_ = *reinterpret_cast<const u32x4*>(smem + w_rd + rd_w + ((j_ * 2 + (S)) * 2 + pl_) * 1024); \
     wf[SET][j_][pl_][0] = t_.x; wf[SET][j_][pl_][1] = t_.y; wf[SET][j_][pl_][2] = t_.z; wf[SET][j_][pl_][3] = t_.w; \
   }
 #define SP_READ_X(S, A_ST)                                                                           \
@@ -253,81 +235,77 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   }
 #define SP_READ_WALL(SET, S)                                                                         \
   {                                                                                                  \
-    SP_READ_W1(SET, S, 0) SP_READ_W1(SET, S, 1) SP_READ_W1(SET, S, 2)                                \
-    SP_READ_W1(SET, S, 3) SP_READ_W1(SET, S, 4) SP_READ_W1(SET, S, 5)                                \
+    SP_READ_W1(SET, S, 0) SP_READ_W1(SET, S, 1)                                                      \
+    if constexpr (NWF > 2) { SP_READ_W1(SET, S, 2) SP_READ_W1(SET, S, 3) }                           \
   }
   // conversion unit U of a k-step: pair (U & 3) of row fragment U >> 2
 #define SP_CONV(SET, U)                                                                              \
   {                                                                                                  \
     constexpr int i_ = (U) >> 2, pr_ = (U) & 3;                                                      \
     const float4 v_ = xr[i_][pr_ >> 1];                                                              \
-    if constexpr ((pr_ & 1) == 0) split_pair(v_.x, v_.y, xp[SET][i_][0][pr_], xp[SET][i_][1][pr_], xp[SET][i_][2][pr_]); \
-    else split_pair(v_.z, v_.w, xp[SET][i_][0][pr_], xp[SET][i_][1][pr_], xp[SET][i_][2][pr_]);     \
+    if constexpr ((pr_ & 1) == 0) split_pair(v_.x, v_.y, xp[SET][i_][0][pr_], xp[SET][i_][1][pr_]);  \
+    else split_pair(v_.z, v_.w, xp[SET][i_][0][pr_], xp[SET][i_][1][pr_]);                          \
   }
 #define SP_PIN() __builtin_amdgcn_sched_barrier(0)
-  // MFMA N of a k-step: products (weight plane, pixel plane) small terms first, accumulators round-robin inside a product
+  // MFMA N of a k-step: products (weight piece, pixel piece) small terms first, accumulators round-robin inside a product
 #define SP_MFMA(SET, N)                                                                              \
   {                                                                                                  \
     constexpr int pr_ = (N) / (MI * NI), ij_ = (N) % (MI * NI), i_ = ij_ / NI, j_ = ij_ % NI;        \
-    constexpr int wp_ = pr_ == 0 ? 0 : pr_ == 1 ? 2 : pr_ == 2 ? 1 : pr_ == 3 ? 0 : pr_ == 4 ? 1 : 0; \
-    constexpr int xp_ = pr_ == 0 ? 2 : pr_ == 1 ? 0 : pr_ == 2 ? 1 : pr_ == 3 ? 1 : pr_ == 4 ? 0 : 0; \
-    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(wf[SET][j_][wp_]), frag(xp[SET][i_][xp_]), acc[i_][j_], 0, 0, 0); \
+    constexpr int wp_ = pr_ == 0 ? 0 : pr_ == 1 ? 1 : 0;                                             \
+    constexpr int xp_ = pr_ == 0 ? 1 : 0;                                                            \
+    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(wf[SET][j_][wp_]), frag(xp[SET][i_][xp_]), acc[i_][j_], 0, 0, 0); \
   }
 
-  // One k-step.  CUR: register set consumed, NXT: set filled for the following step (read at slot 0 from stages
-  // RA / RW, k-step RS of that chunk).  FIRST: the chunk's first step, which carries the barrier and the transfers.
+  // One MFMA slot of a k-step.  CUR: register set consumed, NXT: set filled for the following step.  FIRST: the chunk's
+  // first step, which carries the arrival and the wait of the chunk's synchronisation.
 #define SP_SLOT(CUR, NXT, N, FIRST)                                                                  \
   {                                                                                                  \
-    if constexpr (FIRST && (N) == (SPB ? ARR : BAR)) {                                               \
+    if constexpr (FIRST && (N) == ARR) {                                                             \
+      /* my pieces of the NEXT chunk have landed (the youngest batch may stay in flight; after an epilogue the stores \
+         complete out of order with the transfers, so everything is awaited), my reads of THIS chunk are done */ \
       if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    \
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP) : "memory");                                 \
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP + AP) : "memory");                            \
       drain = false;                                                                                 \
-      if constexpr (SPB) {                                                                           \
-        unsigned long long keep_;                                                                    \
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0" \
-                     : "=&s"(keep_) : "v"(bar_addr), "v"(1u) : "memory");                            \
-      }                                                                                              \
+      unsigned long long keep_;                                                                      \
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0" \
+                   : "=&s"(keep_) : "v"(bar_addr), "v"(1u) : "memory");                              \
     }                                                                                                \
     if constexpr (FIRST && (N) == BAR) {                                                             \
-      if constexpr (SPB) {                                                                           \
-        bar_target += 8u;                                                                            \
-        for (;;) {                                                                                   \
-          unsigned seen_;                                                                            \
-          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen_) : "v"(bar_addr) : "memory"); \
-          if ((int)(__builtin_amdgcn_readfirstlane(seen_) - bar_target) >= 0) break;                 \
-        }                                                                                            \
-      } else {                                                                                       \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
-        __builtin_amdgcn_s_barrier();                                                                \
+      bar_target += 8u;                                                                              \
+      for (;;) {                                                                                     \
+        unsigned seen_;                                                                              \
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen_) : "v"(bar_addr) : "memory"); \
+        if ((int)(__builtin_amdgcn_readfirstlane(seen_) - bar_target) >= 0) break;                   \
       }                                                                                              \
       /* the ticket taken at the tile's start is older than every transfer still in flight here */    \
       if (c == 1 && tid == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(slot_addr), "v"(grid + ticket) : "memory"); \
     }                                                                                                \
     /* transfers: piece k of the wave (weights first) at chunk slot BAR + 1 + k * PSTEP, spread over the rest of the \
-       chunk - the CU's one vector-memory pipe takes 16 cycles per piece, 8 waves x 7 pieces per chunk */ \
+       chunk - the CU's one vector-memory pipe takes 16 cycles per piece */                          \
     constexpr int g_ = (FIRST ? 0 : NM) + (N) - BAR - 1;                                             \
     if constexpr (g_ >= 0 && g_ % PSTEP == 0 && g_ / PSTEP < WP) SP_W_ISSUE(g_ / PSTEP);              \
     if constexpr (g_ >= 0 && g_ % PSTEP == 0 && g_ / PSTEP >= WP && g_ / PSTEP < WP + AP) SP_A_ADDR(g_ / PSTEP - WP, a_off); \
-    if constexpr (g_ >= 1 && (g_ - 1) % PSTEP == 0 && (g_ - 1) / PSTEP >= WP && (g_ - 1) / PSTEP < WP + AP) SP_A_ISSUE((g_ - 1) / PSTEP - WP, a_off); \
-    if constexpr ((N) >= CV0 && ((N) - CV0) % CSTEP == 0 && ((N) - CV0) / CSTEP < UNITS) SP_CONV(NXT, ((N) - CV0) / CSTEP); \
-    constexpr int wsp_ = FIRST ? WSP1 : WSP2;                                                        \
-    if constexpr (WFS && (N) >= 2 && ((N) - 2) % wsp_ == 0 && ((N) - 2) / wsp_ < NI * 3) SP_READ_W1(NXT, FIRST ? 1 : 0, ((N) - 2) / wsp_); \
+    if constexpr (g_ >= ASEP && (g_ - ASEP) % PSTEP == 0 && (g_ - ASEP) / PSTEP >= WP && (g_ - ASEP) / PSTEP < WP + AP) \
+      SP_A_ISSUE((g_ - ASEP) / PSTEP - WP, a_off);                                                   \
+    if constexpr ((N) >= CV0 && (N) - CV0 < UNITS) SP_CONV(NXT, (N) - CV0);                          \
+    if constexpr ((N) >= RD0 && (N) - RD0 < NWF) SP_READ_W1(NXT, FIRST ? 1 : 0, (N) - RD0);          \
     SP_PIN();                                                                                        \
     SP_MFMA(CUR, N);                                                                                 \
     SP_PIN();                                                                                        \
   }
-#define SP_SLOTS4(CUR, NXT, N, FIRST) SP_SLOT(CUR, NXT, N, FIRST) SP_SLOT(CUR, NXT, (N) + 1, FIRST) SP_SLOT(CUR, NXT, (N) + 2, FIRST) SP_SLOT(CUR, NXT, (N) + 3, FIRST)
+#define SP_SLOTS3(CUR, NXT, N, FIRST) SP_SLOT(CUR, NXT, N, FIRST) SP_SLOT(CUR, NXT, (N) + 1, FIRST) SP_SLOT(CUR, NXT, (N) + 2, FIRST)
 #define SP_STEP(CUR, NXT, FIRST)                                                                     \
   {                                                                                                  \
-    SP_SLOTS4(CUR, NXT, 0, FIRST) SP_SLOTS4(CUR, NXT, 4, FIRST) SP_SLOTS4(CUR, NXT, 8, FIRST)        \
-    if constexpr (NM > 12) { SP_SLOTS4(CUR, NXT, 12, FIRST) SP_SLOTS4(CUR, NXT, 16, FIRST) SP_SLOTS4(CUR, NXT, 20, FIRST) } \
+    SP_SLOTS3(CUR, NXT, 0, FIRST) SP_SLOTS3(CUR, NXT, 3, FIRST)                                      \
+    if constexpr (NM > 6) { SP_SLOTS3(CUR, NXT, 6, FIRST) SP_SLOTS3(CUR, NXT, 9, FIRST) }            \
   }
+  static_assert(NM == 6 || NM == 12, "SP_STEP expands 6 or 12 slots");
 
   const unsigned slot_addr = smem_addr + (unsigned)SLOT;
   const unsigned bar_addr = slot_addr + 4;     // arrivals of the split chunk barrier (monotonic)
   unsigned bar_target = 0;
   if (tid == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(bar_addr), "v"(0u) : "memory");
-  // ---- prologue: chunks 0 and 1 of the first tile and the pixels of chunk 2
+  // ---- prologue: chunks 0, 1 and 2 of the first tile
   SP_A_SETUP();
   SP_W_SETUP();
   unsigned a_off = 0;
@@ -338,11 +316,9 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
 #pragma unroll
     for (int i = 0; i < AP; ++i) { SP_A_ADDR(i, a_off); SP_A_ISSUE(i, a_off); }
     SP_A_ADVANCE();
-    if (c < 2) {
 #pragma unroll
-      for (int t = 0; t < WP; ++t) SP_W_ISSUE(t);
-      SP_W_ADVANCE();
-    }
+    for (int t = 0; t < WP; ++t) SP_W_ISSUE(t);
+    SP_W_ADVANCE();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -361,31 +337,30 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   for (;;) {
     const int ticket = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, q_rsrc, q_off, 0, 0);
     for (int c = 0; c < n_chunks; ++c) {
-      // tile hand-over of the streams: the weight stream enters the next tile two chunks before the MFMAs do, the
-      // pixel stream three (the queue slot was written during chunk 1 and published by the barriers since)
+      // tile hand-over of the fetch streams: they enter the next tile three chunks before the MFMAs do (the queue slot
+      // was written during chunk 1 and published by the synchronisations since)
       if (c == n_chunks - 3) {
         int nv;
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nv) : "v"(slot_addr) : "memory");
         next_tile = __builtin_amdgcn_readfirstlane(nv);
         fa_tile = next_tile;
         SP_A_SETUP();
+        fw_tile = next_tile;
+        SP_W_SETUP();
       }
-      if (c == n_chunks - 2) { fw_tile = next_tile; SP_W_SETUP(); }
       SP_A_TAP();
       // first k-step: set 0; its slot 0 reads the second k-step of the same chunk into set 1
       SP_READ_X(1, rd_a);
-      if constexpr (!WFS) SP_READ_WALL(1, 1);
       SP_STEP(0, 1, true)
       // second k-step: set 1; reads the first k-step of the next chunk (published by this chunk's barrier) into set 0
       rd_a = rd_a + A_STAGE == A_RING * A_STAGE ? 0u : rd_a + A_STAGE;
-      rd_w ^= W_STAGE;
+      rd_w = rd_w + W_STAGE == W_RING * W_STAGE ? 0u : rd_w + W_STAGE;
       SP_READ_X(0, rd_a);
-      if constexpr (!WFS) SP_READ_WALL(0, 0);
       SP_STEP(1, 0, false)
       SP_A_ADVANCE();
       SP_W_ADVANCE();
     }
-    // ---- epilogue: bias + residual + ReLU + store
+    // ---- epilogue: 1 / (weight scale) x accumulator + bias + residual, ReLU, store
     {
       const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
       const float floor_v = p.relu ? 0.f : -__builtin_huge_valf();
@@ -409,10 +384,10 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
             const int n = tn * BN + wn * (NI * 32) + j * 32 + 8 * g4 + 4 * fh;
             const unsigned off = (m_ok && n < p.cout_store) ? (unsigned)(m * p.cout_store + n) * 4u : OOB;
             u32x4 pk;
-            pk.x = __float_as_uint(fmaxf(acc[i][j][4 * g4 + 0] + bb[g4].x + __uint_as_float(rr[g4].x), floor_v));
-            pk.y = __float_as_uint(fmaxf(acc[i][j][4 * g4 + 1] + bb[g4].y + __uint_as_float(rr[g4].y), floor_v));
-            pk.z = __float_as_uint(fmaxf(acc[i][j][4 * g4 + 2] + bb[g4].z + __uint_as_float(rr[g4].z), floor_v));
-            pk.w = __float_as_uint(fmaxf(acc[i][j][4 * g4 + 3] + bb[g4].w + __uint_as_float(rr[g4].w), floor_v));
+            pk.x = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 0], p.split_unscale, bb[g4].x + __uint_as_float(rr[g4].x)), floor_v));
+            pk.y = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 1], p.split_unscale, bb[g4].y + __uint_as_float(rr[g4].y)), floor_v));
+            pk.z = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 2], p.split_unscale, bb[g4].z + __uint_as_float(rr[g4].z)), floor_v));
+            pk.w = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 3], p.split_unscale, bb[g4].w + __uint_as_float(rr[g4].w)), floor_v));
             __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, off, 0, 0);
           }
 #pragma unroll
@@ -450,7 +425,7 @@ hipError_t launch_split_cfg(const ConvLaunch& c, hipStream_t s) {
   const int tiles_m = (M + BM - 1) / BM;
   const int tiles_n = (c.cout_store + BN - 1) / BN;
   const int n_tiles = tiles_m * tiles_n;
-  const size_t lds = 3 * (size_t)BM * 128 + 2 * (size_t)BN * 192 + 16;
+  const size_t lds = 3 * (size_t)BM * 128 + 3 * (size_t)BN * 128 + 16;
   static std::atomic<unsigned long long> attr_set{0};
   const unsigned long long dev_bit = (c.device >= 0 && c.device < 64) ? 1ull << c.device : 0ull;
   if (!(attr_set.load(std::memory_order_relaxed) & dev_bit) || !dev_bit) {
@@ -468,7 +443,7 @@ hipError_t launch_split_cfg(const ConvLaunch& c, hipStream_t s) {
 }  // namespace
 
 bool conv_split_applicable(const ConvLaunch& c) {
-  return c.w_split && c.cslice == 32 && c.cin % 32 == 0 && !c.out_nchw && c.splits == 0 && c.k_pad / 32 >= 6 &&
+  return c.w_split && c.split_unscale > 0.f && c.cslice == 32 && c.cin % 32 == 0 && !c.out_nchw && c.splits == 0 && c.k_pad / 32 >= 6 &&
          c.cout_store % 4 == 0 && c.cout_store >= 64 && c.tile_counter && c.num_cu > 0;
 }
 
@@ -480,37 +455,34 @@ hipError_t launch_conv_split(const ConvLaunch& c, hipStream_t s) {
   return launch_split_cfg<256, 128, 4, 2>(c, s);
 }
 
-// Host side: the three bf16 planes of the packed fp32 weights [cout_pad][k_pad] in fragment order:
-// [cout_pad / 32][k_pad / 32][k-step 2][plane 3][lane 64][8] bf16, lane = (row & 31) + 32 * half, element e of the
-// lane = k 16 * step + 8 * half + e of the chunk.  Returns the number of 16-bit words (= 3 * cout_pad * k_pad).
-size_t pack_split_weights(const float* w, int cout_pad, int k_pad, uint16_t* out) {
+// Host side: the two fp16 planes of the packed fp32 weights [cout_pad][k_pad], pre-scaled by `scale` (a power of two),
+// in fragment order: [cout_pad / 32][k_pad / 32][k-step 2][plane 2][lane 64][8] fp16, lane = (row & 31) + 32 * half,
+// element e of the lane = k 16 * step + 8 * half + e of the chunk.  Returns the number of 16-bit words (2 * cout_pad * k_pad).
+size_t pack_split_weights(const float* w, int cout_pad, int k_pad, float scale, uint16_t* out) {
   const int n_chunks = k_pad / 32;
   for (int grp = 0; grp < cout_pad / 32; ++grp)
     for (int kc = 0; kc < n_chunks; ++kc)
       for (int st = 0; st < 2; ++st)
         for (int ln = 0; ln < 64; ++ln)
           for (int e = 0; e < 8; ++e) {
-            const float x = w[(size_t)(grp * 32 + (ln & 31)) * k_pad + kc * 32 + 16 * st + 8 * (ln >> 5) + e];
-            uint32_t u;
-            __builtin_memcpy(&u, &x, 4);
-            const uint32_t uh = u & 0xFFFF0000u;
-            float fh_;
-            __builtin_memcpy(&fh_, &uh, 4);
-            const float r = x - fh_;
-            uint32_t ur;
-            __builtin_memcpy(&ur, &r, 4);
-            const uint32_t um = ur & 0xFFFF0000u;
-            float fm;
-            __builtin_memcpy(&fm, &um, 4);
-            const float l = r - fm;
-            uint32_t ul;
-            __builtin_memcpy(&ul, &l, 4);
-            const size_t base = ((((size_t)grp * n_chunks + kc) * 2 + st) * 3) * 512 + (size_t)ln * 8 + e;
-            out[base] = (uint16_t)(uh >> 16);
-            out[base + 512] = (uint16_t)(um >> 16);
-            out[base + 1024] = (uint16_t)(ul >> 16);
+            const float x = w[(size_t)(grp * 32 + (ln & 31)) * k_pad + kc * 32 + 16 * st + 8 * (ln >> 5) + e] * scale;
+            const _Float16 h0 = (_Float16)x;                  // round to nearest even
+            const _Float16 h1 = (_Float16)(x - (float)h0);    // exact difference, rounded once
+            const size_t base = ((((size_t)grp * n_chunks + kc) * 2 + st) * 2) * 512 + (size_t)ln * 8 + e;
+            __builtin_memcpy(&out[base], &h0, 2);
+            __builtin_memcpy(&out[base + 512], &h1, 2);
           }
-  return (size_t)3 * cout_pad * k_pad;
+  return (size_t)2 * cout_pad * k_pad;
+}
+
+// the power of two that puts the largest weight magnitude in [2^14, 2^15)
+float split_weight_scale(const float* w, size_t n) {
+  float m = 0.f;
+  for (size_t i = 0; i < n; ++i) m = fmaxf(m, fabsf(w[i]));
+  if (!(m > 0.f) || !(m < 3.0e38f)) return 1.f;
+  int e;
+  frexpf(m, &e);                      // m = f * 2^e, f in [0.5, 1)
+  return ldexpf(1.f, 15 - e);
 }
 
 }  // namespace ut

@@ -20,7 +20,8 @@ thread_local std::string g_create_error;
 
 struct ConvW {
   float* w = nullptr;     // device [cout_pad][k_pad]
-  void* w_split = nullptr;   // device: bf16 (hi, mid, lo) planes of w in fragment order (conv_split.hip), eligible layers only
+  void* w_split = nullptr;   // device: the two fp16 planes of w * 2^k in fragment order (conv_split.hip), eligible layers only
+  float split_unscale = 0.f; // 2^-k
   float* bias = nullptr;  // device [cout_pad]
   int cin = 0, cin_pad = 0, cout = 0, cout_pad = 0, cout_store = 0;
   int taps = 1, ksize = 1, stride = 1, pad = 0, k_total = 0, k_pad = 0, cslice = 0;
@@ -92,7 +93,7 @@ struct ut_context {
   int lanes = 1;
   hipStream_t lane_stream[2] = {nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
-  // UT_CONV_FP32 (exact fp32 matrix instructions) or UT_CONV_SPLIT_BF16 (conv_split.hip on the eligible layers)
+  // UT_CONV_FP32 (exact fp32 matrix instructions) or UT_CONV_SPLIT_F16 (conv_split.hip on the eligible layers)
   int conv_arith = UT_CONV_FP32;
   // latency mode (ut_set_latency_mode): launches with far fewer tiles than CUs split K across workgroups
   bool latency_mode = false;
@@ -250,10 +251,12 @@ int pack_conv(ut_handle h, ConvW& cw, const float* w, const float* conv_bias, co
   }
   int rc = upload(h, wp, &cw.w);
   if (rc) return rc;
-  // bf16 planes for the split-bf16 kernel: the layers it takes (channel slice == chunk width, >= 6 chunks, >= 64 channels out)
+  // fp16 planes for the split-fp16 kernel: the layers it takes (channel slice == chunk width, >= 6 chunks, >= 64 channels out)
   if (cw.cslice == 32 && cw.k_pad / 32 >= 6 && cw.cout_store >= 64 && cw.cout_store % 4 == 0) {
-    std::vector<uint16_t> planes((size_t)3 * cw.cout_pad * cw.k_pad);
-    ut::pack_split_weights(wp.data(), cw.cout_pad, cw.k_pad, planes.data());
+    std::vector<uint16_t> planes((size_t)2 * cw.cout_pad * cw.k_pad);
+    const float scale = ut::split_weight_scale(wp.data(), wp.size());
+    cw.split_unscale = 1.0f / scale;
+    ut::pack_split_weights(wp.data(), cw.cout_pad, cw.k_pad, scale, planes.data());
     void* d = nullptr;
     HIPCHK(h, hipMalloc(&d, planes.size() * sizeof(uint16_t)));
     h->allocs.push_back(d);
@@ -444,11 +447,12 @@ int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, fl
     pe.flops = cw.flops_per_pixel * (double)n_img * c.Ho * c.Wo;
     HIPCHK(h, hipEventRecord(pe.a, s));
   }
-  // split-bf16 arithmetic: launches that fill the chip with 256-row tiles (the batched backbone); everything else - and
+  // split-fp16 arithmetic: launches that fill the chip with 256-row tiles (the batched backbone); everything else - and
   // every launch in latency mode - stays on the fp32 matrix instructions
   c.w_split = h->conv_arith != UT_CONV_FP32 ? cw.w_split : nullptr;
+  c.split_unscale = cw.split_unscale;
   const long tiles256 = (((long)n_img * c.Ho * c.Wo + 255) / 256) * ((cw.cout_store + 127) / 128);
-  if (c.w_split && (tiles256 >= 2l * h->num_cu || h->conv_arith == UT_CONV_SPLIT_BF16_ALWAYS) && ut::conv_split_applicable(c))
+  if (c.w_split && (tiles256 >= 2l * h->num_cu || h->conv_arith == UT_CONV_SPLIT_F16_ALWAYS) && ut::conv_split_applicable(c))
     HIPCHK(h, ut::launch_conv_split(c, s));
   else HIPCHK(h, ut::launch_conv_igemm(c, s));
   if (h->profiling) {
@@ -963,7 +967,7 @@ int ut_set_backbone_lanes(ut_handle h, int lanes) {
 }
 
 int ut_set_conv_arithmetic(ut_handle h, int mode) {
-  if (!h || (mode != UT_CONV_FP32 && mode != UT_CONV_SPLIT_BF16 && mode != UT_CONV_SPLIT_BF16_ALWAYS)) return fail(h, UT_E_INVALID, "ut_set_conv_arithmetic: bad argument");
+  if (!h || (mode != UT_CONV_FP32 && mode != UT_CONV_SPLIT_F16 && mode != UT_CONV_SPLIT_F16_ALWAYS)) return fail(h, UT_E_INVALID, "ut_set_conv_arithmetic: bad argument");
   h->conv_arith = mode;
   return UT_OK;
 }

@@ -15,7 +15,8 @@ namespace ut {
 struct ConvLaunch {
   const float* in;     // [n_img, H, W, cin]          (cin % 4 == 0)
   const float* w;      // [cout_pad][k_pad]
-  const void* w_split; // optional: the bf16 (hi, mid, lo) planes of w in fragment order (conv_split.hip), or null
+  const void* w_split; // optional: the two fp16 planes of (w * scale) in fragment order (conv_split.hip), or null
+  float split_unscale; // 1 / scale of w_split
   const float* bias;   // [cout_pad]
   const float* res;    // optional residual, same layout as out
   float* out;          // NHWC [n_img, Ho, Wo, cout_store] or NCHW [n_img, cout_store, Ho*Wo]
@@ -39,10 +40,11 @@ hipError_t launch_conv_igemm(const ConvLaunch& c, hipStream_t s);
 // latency mode: out = act(bias + res + sum of the split-K slabs, in slab order)
 hipError_t launch_splitk_finish(const float* slabs, int n_splits, int m, int cout_store, const float* bias,
                                 const float* res, float* out, int relu, hipStream_t s);
-// the same convolution on the bf16 matrix cores from exact 3-way splits of both operands (conv_split.hip)
+// the same convolution on the fp16 matrix cores from two-piece splits of both operands (conv_split.hip)
 bool conv_split_applicable(const ConvLaunch& c);
 hipError_t launch_conv_split(const ConvLaunch& c, hipStream_t s);
-size_t pack_split_weights(const float* w, int cout_pad, int k_pad, uint16_t* out);
+size_t pack_split_weights(const float* w, int cout_pad, int k_pad, float scale, uint16_t* out);
+float split_weight_scale(const float* w, size_t n);
 // 3x3 stride-1 32->32 channel convs with the halo patch resident in LDS (conv_patch.hip)
 bool conv_patch_applicable(const ConvLaunch& c);
 hipError_t launch_conv_patch(const ConvLaunch& c, hipStream_t s);

@@ -48,9 +48,9 @@ def main():
                     help="backbone lanes: 2 = two half-batches on two internal streams (ut_set_backbone_lanes; +0.3 %%, "
                          "but concurrent launches make per-kernel durations in a rocprof trace overlap, so the default "
                          "keeps one lane and the trace comparable with the roofline leg)")
-    ap.add_argument("--conv", choices=["fp32", "split_bf16"], default="fp32",
+    ap.add_argument("--conv", choices=["fp32", "split_f16"], default="fp32",
                     help="arithmetic of the batched backbone convolutions (ut_set_conv_arithmetic): exact fp32 matrix "
-                         "instructions, or exact 3-way bf16 splits of both operands on the bf16 matrix cores (fp32-level error)")
+                         "instructions, or two-piece fp16 splits of both operands on the fp16 matrix cores (fp32-level error)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend for N>1 (nccl = RCCL over xGMI; gloo only to rehearse the multi-process "
                          "control flow on a box with fewer GPUs than ranks: ranks then share devices)")
@@ -146,7 +146,7 @@ def main():
     value = total_hf / dt
     flops_hf = arch.FLOPS_PER_HANDFRAME_KNOWN if known else arch.FLOPS_PER_HANDFRAME_UNKNOWN
 
-    # split-bf16 mode: the records of the timed workload against the fp32-MFMA mode's on the same batch (checker leg)
+    # split-fp16 mode: the records of the timed workload against the fp32-MFMA mode's on the same batch (checker leg)
     split_check = None
     if args.conv != "fp32" and rank == 0:
         rec_split = hot.step(batch).clone()
@@ -223,7 +223,7 @@ def main():
                        "crops_per_step": n_local * world, "src_image": "480x636 u8 x 4 cameras",
                        "parallelism": f"frame-shard x{world}" + ("" if args.backend == "nccl" else " (gloo rehearsal)"),
                        "outputs_finite": finite},
-            "conv_arithmetic": args.conv, "split_bf16_check": split_check,
+            "conv_arithmetic": args.conv, "split_f16_check": split_check,
             "roofline": roofline, "cpu_baseline": cpu,
             "mpjpe_delta_mm": None if parity is None else parity["mpjpe_delta_mm"], "parity_recording_00": parity,
         }

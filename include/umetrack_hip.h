@@ -83,13 +83,14 @@ int ut_set_backbone_lanes(ut_handle h, int lanes);
 
 /* Arithmetic of the batched backbone convolutions (cin % 32 == 0, >= 64 channels out, launches that fill the chip).
  *  UT_CONV_FP32        v_mfma_f32_32x32x2_f32: the exact fp32 multiply-add chain (default).
- *  UT_CONV_SPLIT_BF16  both operands split exactly into three bf16 pieces (8 + 8 + 8 significand bits), six piece
- *                      products per k on v_mfma_f32_32x32x16_bf16, fp32 accumulation: the terms dropped are below
- *                      2^-24 of a product, so the result carries fp32-level rounding error (not the fp32 chain's bits:
- *                      outputs agree with UT_CONV_FP32 to ~1e-6 relative) at up to 2.67x the matrix rate.
- *  UT_CONV_SPLIT_BF16_ALWAYS  the same kernel also for launches too small to fill the chip (slower there: for tests).
+ *  UT_CONV_SPLIT_F16   both operands as two fp16 pieces (x0 = fp16(x), x1 = fp16(x - x0): 22 significand bits), three
+ *                      piece products per k on v_mfma_f32_32x32x16_f16, fp32 accumulation: the terms dropped are ~2^-22
+ *                      of a product, so the result carries fp32-level rounding error (not the fp32 chain's bits: outputs
+ *                      agree with UT_CONV_FP32 to ~1e-6 relative) at up to 5.3x the matrix rate.  Precondition:
+ *                      |activation| < 65504 (fp16's range; the network's post-BatchNorm activations are O(1..100)).
+ *  UT_CONV_SPLIT_F16_ALWAYS  the same kernel also for launches too small to fill the chip (slower there: for tests).
  * Every other launch (stem, layer1, 1x1 shortcuts, head, and all launches in latency mode) is unaffected. */
-enum { UT_CONV_FP32 = 0, UT_CONV_SPLIT_BF16 = 1, UT_CONV_SPLIT_BF16_ALWAYS = 2 };
+enum { UT_CONV_FP32 = 0, UT_CONV_SPLIT_F16 = 1, UT_CONV_SPLIT_F16_ALWAYS = 2 };
 int ut_set_conv_arithmetic(ut_handle h, int mode);
 
 /* Latency mode for calls on a handful of crops (the per-frame tracker): convolutions whose launch has far fewer tiles

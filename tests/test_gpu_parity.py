@@ -82,16 +82,16 @@ def test_backbone_edge_batches(engine):
 
 @pytest.fixture(scope="module")
 def split_engine():
-    """The same weights with the eligible backbone convolutions on the split-bf16 kernel (conv_split.hip) for EVERY launch
+    """The same weights with the eligible backbone convolutions on the split-fp16 kernel (conv_split.hip) for EVERY launch
     size, so that the small parity cases below go through it."""
     eng = _native.HipEngine(synth.synthetic_state_dict(0), DEV)
-    eng.set_conv_arithmetic("split_bf16_always")
+    eng.set_conv_arithmetic("split_f16_always")
     yield eng
     eng.close()
 
 
-def test_split_bf16_backbone_matches_oracle(engine, split_engine):
-    """conv_split.hip (bf16 matrix cores, exact 3-way operand splits, 6 products) against the fp32 oracle at the fp32
+def test_split_f16_backbone_matches_oracle(engine, split_engine):
+    """conv_split.hip (fp16 matrix cores, two-piece operand splits, 3 products) against the fp32 oracle at the fp32
     kernels' tolerance, on a ragged launch (7 crops: 1008 pixels at 12x12 = three full 256-row tiles and one of 240; 252
     pixels at 6x6 = one partial tile in two column tiles) - and its distance to the fp32-MFMA mode."""
     crops = synth.synthetic_crops(7, seed=3)
@@ -105,7 +105,7 @@ def test_split_bf16_backbone_matches_oracle(engine, split_engine):
     assert torch.equal(split_engine.backbone(_dev(crops)).cpu(), got)       # deterministic
 
 
-def test_split_bf16_large_batch(engine):
+def test_split_f16_large_batch(engine):
     """The default split mode engages on launches that fill the chip: 2048 + 37 crops (ragged last tiles at every
     resolution), against the fp32-MFMA mode on the same crops and the oracle on a few of them."""
     n = 2048 + 37
@@ -115,7 +115,7 @@ def test_split_bf16_large_batch(engine):
     fp32 = engine.backbone(crops)
     eng = _native.HipEngine(synth.synthetic_state_dict(0), DEV)
     try:
-        eng.set_conv_arithmetic("split_bf16")
+        eng.set_conv_arithmetic("split_f16")
         got = eng.backbone(crops)
         assert torch.equal(eng.backbone(crops), got)
         few = eng.backbone(crops[:5])                       # too few tiles: the fp32 kernels, bit for bit
@@ -149,8 +149,8 @@ def _run_steps(engine, known, want_raw=True):
 
 
 @pytest.mark.parametrize("known", [True, False])
-def test_split_bf16_model_matches_reference_goldens(split_engine, golden_dir, known):
-    """The reference's own outputs (tests/golden/model_*.npz), same tolerances, with the backbone on the split-bf16 kernel."""
+def test_split_f16_model_matches_reference_goldens(split_engine, golden_dir, known):
+    """The reference's own outputs (tests/golden/model_*.npz), same tolerances, with the backbone on the split-fp16 kernel."""
     test_model_matches_reference_goldens(split_engine, golden_dir, known)
 
 

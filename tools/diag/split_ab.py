@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic (not part of the product): the split-bf16 convolution (conv_split.hip) against the fp32-MFMA one
+"""Diagnostic (not part of the product): the split-fp16 convolution (conv_split.hip) against the fp32-MFMA one
 (conv_igemm.hip) on one layer shape - error of both against a float64 convolution of the first images, and interleaved timing.
     python tools/diag/split_ab.py <cin> <cout> <hw> <n_img> [ksize] [stride]"""
 import ctypes
@@ -18,18 +18,13 @@ ksize = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 stride = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 # variants of conv_split.hip (text patches of a copy, see VARIANTS) are timed beside the product kernel: name,name,...
 VARIANTS = {
-    # no fp32 -> bf16 conversion work (wrong numbers): what the VALU split costs
-    "noconv": [("  const float ra = a - ", "  hi = ua; mid = ub; lo = ua; return;\n  const float ra = a - ")],
+    # no fp32 -> fp16 conversion work (wrong numbers): what the VALU split costs
+    "noconv": [("  const f16x2 h = ", "  p0 = __float_as_uint(a); p1 = __float_as_uint(b); return;\n  const f16x2 h = ")],
     # no transfers after the prologue (stale operands): what the fetch costs
     "nodma": [("#define SP_A_ISSUE(I, OFF) dma_piece(", "#define SP_A_ISSUE(I, OFF) if (p.k_pad < 0) dma_piece("),
-              ("    if (WTOT % 8 == 0 || q_ < WTOT) {", "    if (p.k_pad < 0) {")],
-    # transfers issued but out of range (zeros land, nothing is fetched): issue cost without the data path
-    "oobdma": [("    OFF = ok ? (unsigned)(a_pix[I] + f_tap_off) * 4u : OOB; ", "    OFF = p.k_pad < 0 ? (unsigned)(a_pix[I] + f_tap_off) * 4u : OOB + (ok ? 0u : 16u); "),
-               ("(unsigned)q_ * 1024u, w_lane, src_);", "(unsigned)q_ * 1024u, OOB, src_);")],
-    # no chunk barrier (only meaningful together with nodma)
-    "nobar": [("      __builtin_amdgcn_s_barrier();  ", "      if (p.k_pad < 0) __builtin_amdgcn_s_barrier();  ")],
+              ("    dma_piece(w_words, smem_addr + W_BASE + fw_stage", "    if (p.k_pad < 0) dma_piece(w_words, smem_addr + W_BASE + fw_stage")],
     # no residual loads and no stores
-    "noepi": [("            __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, off, 0, 0);", "            if (p.k_pad < 0) __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, off, 0, 0);"),
+    "noepi": [("            __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, off, 0, 0);", "            if (p.k_pad < 0 || (pk.x == 0x12345678u && tid == 99999)) __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, off, 0, 0);"),
               ("            rr[g4] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0);", "            rr[g4] = u32x4{0, 0, 0, 0};")],
 }
 variants = [v for v in os.environ.get("SPLIT_VARIANTS", "").split(",") if v]
@@ -74,7 +69,7 @@ wp[:cout] = w_oihw.reshape(cout, cin // 32, 32, ksize * ksize).permute(0, 1, 3, 
 bias = torch.zeros(cout_pad)
 bias[:cout] = torch.randn(cout) * 0.1
 res = torch.rand(n_img, ho, ho, cout, device=dev)
-split = np.zeros(3 * cout_pad * k_total, np.uint16)
+split = np.zeros(2 * cout_pad * k_total, np.uint16)
 assert lib.split_pack(wp.numpy().ctypes.data_as(ctypes.c_void_p), cout_pad, k_total, split.ctypes.data_as(ctypes.c_void_p)) == 0
 w_d, b_d = wp.to(dev), bias.to(dev)
 s_d = torch.from_numpy(split.view(np.int16)).to(dev)
@@ -92,7 +87,7 @@ nref = min(n_img, 6)
 ref = torch.nn.functional.conv2d(x[:nref].permute(0, 3, 1, 2).double().cpu(), w_oihw.double(), bias[:cout].double(), stride, ksize // 2)
 ref = torch.relu(ref.permute(0, 2, 3, 1) + res[:nref].double().cpu())
 outs = {}
-for mode, name in ((0, "fp32 mfma"), (1, "split bf16x6")):
+for mode, name in ((0, "fp32 mfma"), (1, "split f16x3")):
     out.fill_(float("nan"))
     run(mode)
     torch.cuda.synchronize()
@@ -100,10 +95,10 @@ for mode, name in ((0, "fp32 mfma"), (1, "split bf16x6")):
     outs[name] = o
     assert torch.isfinite(o).all(), name
     print(f"{name:14s} max |out - f64 conv| over {nref} images = {float((o[:nref].double().cpu() - ref).abs().max()):.3e}")
-a, b = outs["fp32 mfma"], outs["split bf16x6"]
+a, b = outs["fp32 mfma"], outs["split f16x3"]
 print(f"max |split - fp32| over all {n_img} images = {float((a - b).abs().max()):.3e}   (|out| max {float(a.abs().max()):.2f})")
 flops = 2.0 * n_img * ho * ho * cout * k_total
-cases = [("fp32 mfma", 0, lib), ("split bf16x6", 1, lib)] + [(v, 1, l) for v, l in vlibs.items()]
+cases = [("fp32 mfma", 0, lib), ("split f16x3", 1, lib)] + [(v, 1, l) for v, l in vlibs.items()]
 times = {name: [] for name, _m, _l in cases}
 for rnd in range(10):
     for name, mode, l in cases:

@@ -4,14 +4,17 @@
 
 #include "ut_kernels.h"
 
+static float g_unscale = 1.f;
 extern "C" int split_pack(const float* w, int cout_pad, int k_pad, uint16_t* out) {
-  return (int)(ut::pack_split_weights(w, cout_pad, k_pad, out) != (size_t)3 * cout_pad * k_pad);
+  const float scale = ut::split_weight_scale(w, (size_t)cout_pad * k_pad);
+  g_unscale = 1.f / scale;
+  return (int)(ut::pack_split_weights(w, cout_pad, k_pad, scale, out) != (size_t)2 * cout_pad * k_pad);
 }
 
 extern "C" int conv_diag2(const float* in, const float* w, const void* w_split, const float* bias, const float* res,
                           float* out, int n_img, int hw, int cin, int cout, int ksize, int stride, int relu, int mode) {
   ut::ConvLaunch c{};
-  c.in = in; c.w = w; c.w_split = w_split; c.bias = bias; c.res = res; c.out = out;
+  c.in = in; c.w = w; c.w_split = w_split; c.split_unscale = g_unscale; c.bias = bias; c.res = res; c.out = out;
   c.n_img = n_img; c.H = hw; c.W = hw; c.cin = cin;
   c.ksize = ksize; c.stride = stride; c.pad = ksize / 2;
   c.Ho = (hw + 2 * c.pad - ksize) / stride + 1; c.Wo = c.Ho;
