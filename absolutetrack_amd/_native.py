@@ -20,7 +20,7 @@ EXPORTS = (
     "ut_weight_blob_floats", "ut_create", "ut_destroy", "ut_last_error", "ut_reserve",
     "ut_set_backbone_chunk", "ut_warp_crops", "ut_backbone", "ut_fuse_temporal_regress",
     "ut_reset_memory", "ut_get_memory", "ut_fk", "ut_gen_crop_cameras", "ut_gen_crop_matrices",
-    "ut_resample_homography", "ut_keypoint_metrics", "ut_profile_begin", "ut_profile_end",
+    "ut_resample_homography", "ut_keypoint_metrics", "ut_profile_begin", "ut_profile_end", "ut_profile_end_by_kind",
     "ut_set_index_checks", "ut_poll_status", "ut_warp_backbone", "ut_set_latency_mode", "ut_set_conv_arithmetic",
     "ut_set_backbone_lanes",
 )
@@ -86,6 +86,9 @@ def load_library() -> ctypes.CDLL:
     lib.ut_keypoint_metrics.argtypes = [vp, f32p, f32p, vp, i32, i32, vp, vp, vp, vp, vp]
     lib.ut_profile_begin.restype = i32
     lib.ut_profile_begin.argtypes = [vp, vp]
+    lib.ut_profile_end_by_kind.restype = i32
+    lib.ut_profile_end_by_kind.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
+                                           ctypes.POINTER(ctypes.c_double)]
     lib.ut_profile_end.restype = i32
     lib.ut_profile_end.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
                                    ctypes.POINTER(ctypes.c_double)]
@@ -507,6 +510,12 @@ class HipEngine:
 
     def profile_begin(self):
         self._check(self.lib.ut_profile_begin(self._h, _stream(self.device)), "ut_profile_begin")
+
+    def profile_end_by_kind(self):
+        """[(ms, launches, flops) of the fp32-matrix-instruction launches, (...) of the split-fp16 launches]"""
+        ms, n, fl = (ctypes.c_double * 2)(), (ctypes.c_int64 * 2)(), (ctypes.c_double * 2)()
+        self._check(self.lib.ut_profile_end_by_kind(self._h, _stream(self.device), ms, n, fl), "ut_profile_end_by_kind")
+        return [(ms[k], n[k], fl[k]) for k in range(2)]
 
     def profile_end(self):
         ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()

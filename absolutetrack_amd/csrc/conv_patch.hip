@@ -62,6 +62,21 @@ __device__ __forceinline__ u32x4 rsrc_words(const void* base, unsigned bytes) {
 }
 }  // namespace
 
+// SPLIT: the arithmetic of conv_split.hip (two fp16 pieces per operand, three products per k on v_mfma_f32_32x32x16_f16,
+// fp32 accumulation) instead of the fp32 matrix instruction: the resident weights are the two fp16 planes of
+// ConvLaunch::w_split in fragment order (the same 36 KB), the patch stays fp32 in LDS and is split in registers, the
+// accumulators hold scale x (sum) and start at scale x (bias + residual).  Nine taps x 6 MFMAs of 32 cycles instead of
+// 9 x 16 of 64: the kernel is then bound by the tile's HBM traffic (patch in, residual in, tile out), not by the matrix pipe.
+typedef _Float16 f16x8p __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2p __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair_p(float a, float b, unsigned& p0, unsigned& p1) {
+  const f16x2p h = __builtin_bit_cast(f16x2p, __builtin_amdgcn_cvt_pkrtz(a, b));
+  const float ra = a - (float)h[0], rb = b - (float)h[1];
+  p0 = __builtin_bit_cast(unsigned, h);
+  p1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+}
+
+template <bool SPLIT>
 __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p, int tiles_x, int tiles_per_img, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* w_lds = smem;                                  // [9*32 rows][32]
@@ -87,7 +102,8 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
   const unsigned smem_addr = (unsigned)(unsigned long)(lds_f32p*)smem;
 
   const u32x4 in_words = rsrc_words(p.in, (unsigned)((size_t)M * C * sizeof(float)));
-  const u32x4 w_words = rsrc_words(p.w, (unsigned)((size_t)p.cout_pad * p.k_pad * sizeof(float)));
+  const u32x4 w_words = SPLIT ? rsrc_words(p.w_split, (unsigned)(W_FLOATS * 4))
+                              : rsrc_words(p.w, (unsigned)((size_t)p.cout_pad * p.k_pad * sizeof(float)));
   const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.res ? p.res : p.bias), 0, p.res ? (int)((size_t)M * C * sizeof(float)) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t o_rsrc =
@@ -95,6 +111,10 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
 
   // ---- weights -> LDS once (row = tap*32 + n, swizzle by n)
   for (int k = wave; k < W_INSTR; k += NW) {
+    if constexpr (SPLIT) {     // rows 0..31 of w_split: [tap][k-step][plane][lane][8 halves], one 1-KB block per piece
+      dma16p(w_words, smem_addr + (unsigned)(k * 1024), (unsigned)(k * 1024 + lane * 16));
+      continue;
+    }
     const int e = k * 64 + lane;
     const int row = e >> 3, cpos = e & 7;
     const int n = row & 31, tap = row >> 5;
@@ -166,6 +186,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
     for (int g4 = 0; g4 < 4; ++g4)
       res_raw[g4] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, (unsigned)(m * C + 8 * g4 + 4 * fh) * 4u, 0, 0);
   };
+  const float acc_scale = SPLIT ? 1.0f / p.split_unscale : 1.0f;      // a power of two
   auto init_combine = [&]() {
     f32x16 v;
 #pragma unroll
@@ -174,6 +195,10 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
       v[4 * g4 + 1] = bias_raw[g4].y + __uint_as_float(res_raw[g4].y);
       v[4 * g4 + 2] = bias_raw[g4].z + __uint_as_float(res_raw[g4].z);
       v[4 * g4 + 3] = bias_raw[g4].w + __uint_as_float(res_raw[g4].w);
+    }
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] *= acc_scale;
     }
     return v;
   };
@@ -205,6 +230,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
       const int n = 8 * g4 + 4 * fh;                                                                 \
       u32x4 pk;                                                                                      \
       float v0 = acc[4 * g4], v1 = acc[4 * g4 + 1], v2 = acc[4 * g4 + 2], v3 = acc[4 * g4 + 3];      \
+      if constexpr (SPLIT) { v0 *= p.split_unscale; v1 *= p.split_unscale; v2 *= p.split_unscale; v3 *= p.split_unscale; } \
       if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); } \
       pk.x = __float_as_uint(v0); pk.y = __float_as_uint(v1); pk.z = __float_as_uint(v2); pk.w = __float_as_uint(v3); \
       __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, (unsigned)(m_ * C + n) * 4u, 0, 0);         \
@@ -232,45 +258,96 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
     // 9 taps x 4 k-groups, fragments double buffered in registers.  The requests for the NEXT tile (patch
     // pieces, residual) are slipped in between MFMA groups of taps 0..6 so that their address arithmetic and
     // issue run in the shadow of MFMAs already queued.
-    float4 wfX, pfX, wfY, pfY;
+    if constexpr (!SPLIT) {
+      float4 wfX, pfX, wfY, pfY;
 #define UTP_READ(SET, TAP, Q)                                                                        \
-  {                                                                                                  \
-    const int pidx_ = pbase + ((TAP) / 3) * PW + ((TAP) % 3);                                        \
-    pf##SET = *reinterpret_cast<const float4*>(patch + pidx_ * C + 4 * ((2 * (Q) + fh) ^ ((pidx_ >> 1) & 7))); \
-    wf##SET = *reinterpret_cast<const float4*>(w_lds + (TAP) * C * C + w_off[Q]);                    \
-  }
-#define UTP_MFMA(SET)                                                                                \
-  {                                                                                                  \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf##SET.x, pf##SET.x, acc, 0, 0, 0);                  \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf##SET.y, pf##SET.y, acc, 0, 0, 0);                  \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf##SET.z, pf##SET.z, acc, 0, 0, 0);                  \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf##SET.w, pf##SET.w, acc, 0, 0, 0);                  \
-  }
-#define UTP_PIN() __builtin_amdgcn_sched_barrier(0)
-    UTP_READ(X, 0, 0);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      UTP_READ(Y, tap, 1); UTP_PIN(); UTP_MFMA(X); UTP_PIN();
-      if (has_next && tap < MAXP) issue_piece(tap, n_row0, n_y0, n_x0, cur ^ 1);
-      if (has_next && tap == MAXP) init_load(n_row0, n_y0, n_x0);
-      UTP_READ(X, tap, 2); UTP_PIN(); UTP_MFMA(Y); UTP_PIN();
-      UTP_READ(Y, tap, 3); UTP_PIN(); UTP_MFMA(X); UTP_PIN();
-      if (tap < 8) {
-        UTP_READ(X, tap + 1, 0);
-      } else {
-        // everything requested for the next tile was issued at least two taps ago: drain the counter, publish
-        // the ticket and combine bias+residual NOW, in front of the last MFMA group and of the stores (vmcnt
-        // counts stores too: waiting at the barrier would cost every wave a write round trip per tile)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0) slot_write(cur, grid + ticket);
-        if (has_next) ready = init_combine();
-        asm volatile("" : "+v"(ready));
-      }
-      UTP_PIN(); UTP_MFMA(Y); UTP_PIN();
+    {                                                                                                  \
+      const int pidx_ = pbase + ((TAP) / 3) * PW + ((TAP) % 3);                                        \
+      pf##SET = *reinterpret_cast<const float4*>(patch + pidx_ * C + 4 * ((2 * (Q) + fh) ^ ((pidx_ >> 1) & 7))); \
+      wf##SET = *reinterpret_cast<const float4*>(w_lds + (TAP) * C * C + w_off[Q]);                    \
     }
+#define UTP_MFMA(SET)                                                                                \
+    {                                                                                                  \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf##SET.x, pf##SET.x, acc, 0, 0, 0);                  \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf##SET.y, pf##SET.y, acc, 0, 0, 0);                  \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf##SET.z, pf##SET.z, acc, 0, 0, 0);                  \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf##SET.w, pf##SET.w, acc, 0, 0, 0);                  \
+    }
+#define UTP_PIN() __builtin_amdgcn_sched_barrier(0)
+      UTP_READ(X, 0, 0);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        UTP_READ(Y, tap, 1); UTP_PIN(); UTP_MFMA(X); UTP_PIN();
+        if (has_next && tap < MAXP) issue_piece(tap, n_row0, n_y0, n_x0, cur ^ 1);
+        if (has_next && tap == MAXP) init_load(n_row0, n_y0, n_x0);
+        UTP_READ(X, tap, 2); UTP_PIN(); UTP_MFMA(Y); UTP_PIN();
+        UTP_READ(Y, tap, 3); UTP_PIN(); UTP_MFMA(X); UTP_PIN();
+        if (tap < 8) {
+          UTP_READ(X, tap + 1, 0);
+        } else {
+          // everything requested for the next tile was issued at least two taps ago: drain the counter, publish
+          // the ticket and combine bias+residual NOW, in front of the last MFMA group and of the stores (vmcnt
+          // counts stores too: waiting at the barrier would cost every wave a write round trip per tile)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (tid == 0) slot_write(cur, grid + ticket);
+          if (has_next) ready = init_combine();
+          asm volatile("" : "+v"(ready));
+        }
+        UTP_PIN(); UTP_MFMA(Y); UTP_PIN();
+      }
 #undef UTP_READ
 #undef UTP_MFMA
 #undef UTP_PIN
+    } else {
+      // 9 taps x 2 k-steps of 16: per step two b128 reads of the lane's 8 patch values, the split, the two weight
+      // planes (one conflict-free b128 each) and three MFMAs; the next step's reads are issued ahead of the MFMAs
+      float4 prX[2], prY[2];
+      u32x4 wqX[2], wqY[2];
+      const char* w_bytes = reinterpret_cast<const char*>(smem) + lane * 16;
+#define UTS_READ(SET, TAP, S)                                                                        \
+  {                                                                                                  \
+    const int pidx_ = pbase + ((TAP) / 3) * PW + ((TAP) % 3);                                        \
+    const int sw_ = (pidx_ >> 1) & 7;                                                                \
+    pr##SET[0] = *reinterpret_cast<const float4*>(patch + pidx_ * C + 4 * ((4 * (S) + 2 * fh) ^ sw_));     \
+    pr##SET[1] = *reinterpret_cast<const float4*>(patch + pidx_ * C + 4 * ((4 * (S) + 2 * fh + 1) ^ sw_)); \
+    wq##SET[0] = *reinterpret_cast<const u32x4*>(w_bytes + (((TAP) * 2 + (S)) * 2 + 0) * 1024);      \
+    wq##SET[1] = *reinterpret_cast<const u32x4*>(w_bytes + (((TAP) * 2 + (S)) * 2 + 1) * 1024);      \
+  }
+#define UTS_MFMA(SET)                                                                                \
+  {                                                                                                  \
+    unsigned a0_, a1_, b0_, b1_, c0_, c1_, d0_, d1_;                                                 \
+    split_pair_p(pr##SET[0].x, pr##SET[0].y, a0_, a1_);                                              \
+    split_pair_p(pr##SET[0].z, pr##SET[0].w, b0_, b1_);                                              \
+    split_pair_p(pr##SET[1].x, pr##SET[1].y, c0_, c1_);                                              \
+    split_pair_p(pr##SET[1].z, pr##SET[1].w, d0_, d1_);                                              \
+    u32x4 p0_, p1_;                                                                                  \
+    p0_.x = a0_; p0_.y = b0_; p0_.z = c0_; p0_.w = d0_;                                              \
+    p1_.x = a1_; p1_.y = b1_; p1_.z = c1_; p1_.w = d1_;                                              \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8p, wq##SET[0]), __builtin_bit_cast(f16x8p, p1_), acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8p, wq##SET[1]), __builtin_bit_cast(f16x8p, p0_), acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8p, wq##SET[0]), __builtin_bit_cast(f16x8p, p0_), acc, 0, 0, 0); \
+  }
+#define UTS_PIN() __builtin_amdgcn_sched_barrier(0)
+      UTS_READ(X, 0, 0);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        UTS_READ(Y, tap, 1); UTS_PIN(); UTS_MFMA(X); UTS_PIN();
+        if (has_next && tap < MAXP) issue_piece(tap, n_row0, n_y0, n_x0, cur ^ 1);
+        if (has_next && tap == MAXP) init_load(n_row0, n_y0, n_x0);
+        if (tap < 8) {
+          UTS_READ(X, tap + 1, 0);
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (tid == 0) slot_write(cur, grid + ticket);
+          if (has_next) ready = init_combine();
+          asm volatile("" : "+v"(ready));
+        }
+        UTS_PIN(); UTS_MFMA(Y); UTS_PIN();
+      }
+#undef UTS_READ
+#undef UTS_MFMA
+#undef UTS_PIN
+    }
     // epilogue: (ReLU) + 4 x 16-byte stores per lane.  Waves 0-3 store right after their MFMAs; waves 4-7 (the
     // SIMD partners of 0-3: a workgroup's waves w and w+4 share a SIMD) keep the tile in registers and store it at
     // the top of the NEXT tile instead, so that within a barrier interval one partner stores while the other
@@ -306,14 +383,20 @@ hipError_t launch_conv_patch(const ConvLaunch& c, hipStream_t s) {
   static std::atomic<unsigned long long> attr_set{0};
   const unsigned long long dev_bit = (c.device >= 0 && c.device < 64) ? 1ull << c.device : 0ull;
   if (!(attr_set.load(std::memory_order_relaxed) & dev_bit) || !dev_bit) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c32_patch_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c32_patch_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c32_patch_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set.fetch_or(dev_bit, std::memory_order_relaxed);
   }
   int grid = c.num_cu;           // one 512-thread workgroup per CU (LDS: 121 KB)
   if (grid > n_tiles) grid = n_tiles;
-  hipLaunchKernelGGL(conv3x3_c32_patch_kernel, dim3(grid), dim3(64 * NW), lds, s, c, tiles_x, tiles_per_img, n_tiles);
+  if (c.w_split && c.split_unscale > 0.f)      // split-fp16 arithmetic (ut_set_conv_arithmetic)
+    hipLaunchKernelGGL(conv3x3_c32_patch_kernel<true>, dim3(grid), dim3(64 * NW), lds, s, c, tiles_x, tiles_per_img, n_tiles);
+  else
+    hipLaunchKernelGGL(conv3x3_c32_patch_kernel<false>, dim3(grid), dim3(64 * NW), lds, s, c, tiles_x, tiles_per_img, n_tiles);
   return hipGetLastError();
 }
 

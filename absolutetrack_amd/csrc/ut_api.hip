@@ -40,7 +40,8 @@ struct Regressor {
   int c = 0, d = 0;
 };
 
-struct ProfEvent { hipEvent_t a, b; double flops; };
+struct ProfEvent { hipEvent_t a, b; double flops;   int kind = 0;   // 0: fp32 matrix-instruction kernels, 1: split-fp16 kernels
+};
 
 }  // namespace
 
@@ -251,8 +252,9 @@ int pack_conv(ut_handle h, ConvW& cw, const float* w, const float* conv_bias, co
   }
   int rc = upload(h, wp, &cw.w);
   if (rc) return rc;
-  // fp16 planes for the split-fp16 kernel: the layers it takes (channel slice == chunk width, >= 6 chunks, >= 64 channels out)
-  if (cw.cslice == 32 && cw.k_pad / 32 >= 6 && cw.cout_store >= 64 && cw.cout_store % 4 == 0) {
+  // fp16 planes for the split-fp16 kernels: the layers they take (channel slice == chunk width, >= 6 chunks: the 3x3
+  // convolutions of the backbone; conv_split.hip from 64 channels out, conv_patch.hip's split instantiation for layer1)
+  if (cw.cslice == 32 && cw.k_pad / 32 >= 6 && cw.cout_store >= 32 && cw.cout_store % 4 == 0) {
     std::vector<uint16_t> planes((size_t)2 * cw.cout_pad * cw.k_pad);
     const float scale = ut::split_weight_scale(wp.data(), wp.size());
     cw.split_unscale = 1.0f / scale;
@@ -449,11 +451,12 @@ int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, fl
   }
   // split-fp16 arithmetic: launches that fill the chip with 256-row tiles (the batched backbone); everything else - and
   // every launch in latency mode - stays on the fp32 matrix instructions
-  c.w_split = h->conv_arith != UT_CONV_FP32 ? cw.w_split : nullptr;
-  c.split_unscale = cw.split_unscale;
   const long tiles256 = (((long)n_img * c.Ho * c.Wo + 255) / 256) * ((cw.cout_store + 127) / 128);
-  if (c.w_split && (tiles256 >= 2l * h->num_cu || h->conv_arith == UT_CONV_SPLIT_F16_ALWAYS) && ut::conv_split_applicable(c))
-    HIPCHK(h, ut::launch_conv_split(c, s));
+  const bool split = h->conv_arith == UT_CONV_SPLIT_F16_ALWAYS || (h->conv_arith == UT_CONV_SPLIT_F16 && tiles256 >= 2l * h->num_cu);
+  c.w_split = split && !h->latency_mode ? cw.w_split : nullptr;
+  c.split_unscale = cw.split_unscale;
+  pe.kind = c.w_split && (ut::conv_split_applicable(c) || ut::conv_patch_applicable(c)) ? 1 : 0;
+  if (c.w_split && ut::conv_split_applicable(c)) HIPCHK(h, ut::launch_conv_split(c, s));
   else HIPCHK(h, ut::launch_conv_igemm(c, s));
   if (h->profiling) {
     HIPCHK(h, hipEventRecord(pe.b, s));
@@ -1028,6 +1031,23 @@ int ut_profile_end(ut_handle h, void* stream, double* conv_ms_total, int64_t* co
   if (conv_ms_total) *conv_ms_total = ms;
   if (conv_launches) *conv_launches = (int64_t)h->prof.size();
   if (conv_flops_total) *conv_flops_total = fl;
+  for (auto& pe : h->prof) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+  h->prof.clear();
+  return UT_OK;
+}
+
+int ut_profile_end_by_kind(ut_handle h, void* stream, double* ms2, int64_t* launches2, double* flops2) {
+  if (!h || !ms2 || !launches2 || !flops2) return UT_E_INVALID;
+  ON_DEVICE_OF(h);
+  h->profiling = false;
+  HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+  for (int k = 0; k < 2; ++k) { ms2[k] = 0; launches2[k] = 0; flops2[k] = 0; }
+  for (auto& pe : h->prof) {
+    float t = 0;
+    HIPCHK(h, hipEventElapsedTime(&t, pe.a, pe.b));
+    const int k = pe.kind ? 1 : 0;
+    ms2[k] += t; flops2[k] += pe.flops; launches2[k] += 1;
+  }
   for (auto& pe : h->prof) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
   h->prof.clear();
   return UT_OK;

@@ -31,6 +31,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense fp16/bf16 MFMA; the split kernels spend 3 fp16 MFMA flops per flop
 
 
 def main():
@@ -48,7 +49,7 @@ def main():
                     help="backbone lanes: 2 = two half-batches on two internal streams (ut_set_backbone_lanes; +0.3 %%, "
                          "but concurrent launches make per-kernel durations in a rocprof trace overlap, so the default "
                          "keeps one lane and the trace comparable with the roofline leg)")
-    ap.add_argument("--conv", choices=["fp32", "split_f16"], default="fp32",
+    ap.add_argument("--conv", choices=["fp32", "split_f16"], default="split_f16",
                     help="arithmetic of the batched backbone convolutions (ut_set_conv_arithmetic): exact fp32 matrix "
                          "instructions, or two-piece fp16 splits of both operands on the fp16 matrix cores (fp32-level error)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -120,22 +121,27 @@ def main():
         rec = hot.step(batch)
         return pipeline.gather_records(rec, world, equal_counts=equal)
 
-    for _ in range(args.warmup):
-        out = one_step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = one_step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed_run():
+        out = None
+        for _ in range(args.warmup):
+            out = one_step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = one_step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
+    dt, out = timed_run()
     hot.check()            # deferred index checks of every step above
     assert out.shape == (s_local * world, pipeline.RECORD)
     finite = bool(torch.isfinite(out).all().item())
@@ -146,14 +152,18 @@ def main():
     value = total_hf / dt
     flops_hf = arch.FLOPS_PER_HANDFRAME_KNOWN if known else arch.FLOPS_PER_HANDFRAME_UNKNOWN
 
-    # split-fp16 mode: the records of the timed workload against the fp32-MFMA mode's on the same batch (checker leg)
-    split_check = None
-    if args.conv != "fp32" and rank == 0:
+    # split-fp16 mode: the same K steps timed with the exact-fp32 convolutions (every rank, same barriers), and the records
+    # of the timed workload against that mode's on the same batch
+    split_check, fp32_mode = None, None
+    if args.conv != "fp32":
         rec_split = hot.step(batch).clone()
         eng.set_conv_arithmetic("fp32")
+        dt32, _ = timed_run()
         rec_fp32 = hot.step(batch).clone()
         eng.set_conv_arithmetic(args.conv)
         hot.check()
+        fp32_mode = {"value": round(total_hf / dt32, 1), "unit": "hand-frames/s", "ms_per_step": round(dt32 / args.steps * 1e3, 3),
+                     "what": "the same steps with ut_set_conv_arithmetic(UT_CONV_FP32): every convolution on v_mfma_f32_32x32x2_f32"}
         split_check = {"against": "the same step with UT_CONV_FP32 (itself pinned to the oracle by tests/ and parity_recording_00)",
                        "hand_frames": int(rec_split.shape[0]),
                        "max_joint_angle_diff_rad": float((rec_split[:, :22] - rec_fp32[:, :22]).abs().max()),
@@ -168,7 +178,9 @@ def main():
         n_prof = 2
         for _ in range(n_prof):
             hot.step(batch)
-        ms, launches, flops = eng.profile_end()
+        kinds = eng.profile_end_by_kind()
+        split_kind = args.conv != "fp32" and kinds[1][1] > 0
+        ms, launches, flops = kinds[1] if split_kind else kinds[0]
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         # HBM bytes per launch cannot be measured by this process: they come from separate rocprofv3 --pmc passes of
         # this same command (FETCH_SIZE and WRITE_SIZE cannot share a pass), summarised by tools/pmc_traffic.py into
@@ -176,25 +188,39 @@ def main():
         traffic, traffic_source = None, None
         prof_dir = os.path.join(ROOT, "profiles")
         cands = sorted(f for f in (os.listdir(prof_dir) if os.path.isdir(prof_dir) else []) if f.endswith("_conv_traffic.json"))
-        if cands and f_local == 1024 and known:
+        if cands and f_local == 1024 and known and not split_kind:
             tj = json.load(open(os.path.join(prof_dir, cands[-1])))
             traffic = tj.get("traffic_bytes_per_launch")
             traffic_source = (f"profiles/{cands[-1]}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `{tj.get('label', '')}` "
                               "(an earlier run of this command, not this process); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024")
-        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (all instantiations) + conv3x3_c32_patch_kernel (layer1)",
-                    "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+        peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split_kind else PEAK_FP32_MFMA_TFLOPS
+        roofline = {"bound": "mfma",
+                    "kernel": ("conv_split_kernel (both instantiations) + conv3x3_c32_patch_kernel<true> (layer1): two-piece fp16 "
+                               "splits, 3 products per k on v_mfma_f32_32x32x16_f16" if split_kind else
+                               "conv_igemm_kernel (all instantiations) + conv3x3_c32_patch_kernel (layer1)"),
+                    "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
+                    "peak_source": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 products per algorithmic flop" if split_kind else
+                                    "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+                    "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_source": traffic_source,
                     "launches_per_step": launches // n_prof, "avg_launch_ms": round(ms / max(launches, 1), 5),
                     "flops_per_launch_avg": flops / max(launches, 1),
                     "whole_step_tflops": round(value * flops_hf / 1e12, 3)}
+        if split_kind and kinds[0][0] > 0:
+            ms0, l0, f0 = kinds[0]
+            roofline["fp32_kernels_in_this_mode"] = {
+                "what": "1x1 shortcut convolutions, projection and head: still conv_igemm_kernel on the fp32 matrix instructions",
+                "launches_per_step": l0 // n_prof, "ms_per_step": round(ms0 / n_prof, 4),
+                "achieved": round(f0 / (ms0 * 1e-3) / 1e12, 3), "peak": PEAK_FP32_MFMA_TFLOPS}
 
-    cpu = None
+    cpu, batched = None, None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         from oracle import checks
         # the GPU box gives one GPU a 16-CPU share although os.cpu_count() reports the whole host
         threads = min(os.cpu_count() or 1, 16)
         r = checks.time_oracle(sd, args.cpu_frames, threads)
+        # the batched path against the oracle's outputs for the frames it has just computed, in both arithmetics
+        batched = [checks.batched_parity(sd, r, str(device), m) for m in (("fp32", "split_f16") if known else ())]
         cpu = {"value": round(r["hand_frames"] / r["seconds"], 2), "unit": "hand-frames/s", "cores": threads,
                "kind": "port",
                "sample": f"{args.cpu_frames} label frames ({r['hand_frames']} hand-frames) of the same workload, "
@@ -214,7 +240,9 @@ def main():
         line = {
             "metric": "hand-frames/sec", "value": round(value, 1), "unit": "hand-frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.conv == "fp32" else "f32 (backbone products as two fp16 pieces per operand, fp32 accumulation)",
+            "data": "synthetic",
             "config": {"workload": "4 fisheye cameras x 2 hands per frame, 2 views per hand, 96x96 crops, "
                                    f"{'known' if known else 'unknown'}-skeleton path, full hot path "
                                    "(resample+backbone+head+FK) + all-gather of records"
@@ -223,7 +251,8 @@ def main():
                        "crops_per_step": n_local * world, "src_image": "480x636 u8 x 4 cameras",
                        "parallelism": f"frame-shard x{world}" + ("" if args.backend == "nccl" else " (gloo rehearsal)"),
                        "outputs_finite": finite},
-            "conv_arithmetic": args.conv, "split_f16_check": split_check,
+            "conv_arithmetic": args.conv, "split_f16_check": split_check, "exact_fp32_mode": fp32_mode,
+            "parity_batched_vs_oracle": batched,
             "roofline": roofline, "cpu_baseline": cpu,
             "mpjpe_delta_mm": None if parity is None else parity["mpjpe_delta_mm"], "parity_recording_00": parity,
         }

@@ -242,6 +242,9 @@ int ut_keypoint_metrics(ut_handle h, const float* gt, const float* tracked, cons
 int ut_profile_begin(ut_handle h, void* stream);
 int ut_profile_end(ut_handle h, void* stream, double* conv_ms_total, int64_t* conv_launches,
                    double* conv_flops_total);
+/* The same, separately for [0] the launches on the fp32 matrix instructions and [1] the split-fp16 launches
+ * (ut_set_conv_arithmetic): three arrays of two. */
+int ut_profile_end_by_kind(ut_handle h, void* stream, double* ms2, int64_t* launches2, double* flops2);
 
 #ifdef __cplusplus
 }

@@ -97,7 +97,34 @@ def time_oracle(sd_np, n_frames: int, threads: int) -> Dict[str, float]:
     t0 = time.perf_counter()
     out = oracle_frames(sd_np, lab, hm_np, frame_ids, frames)
     dt = time.perf_counter() - t0
-    return {"seconds": dt, "hand_frames": int(out["keypoints_mm"].shape[0])}
+    return {"seconds": dt, "hand_frames": int(out["keypoints_mm"].shape[0]), "oracle": out, "frames": frames, "frame_ids": frame_ids}
+
+
+def batched_parity(sd_np, timed: Dict, device: str, conv: str) -> Dict[str, float]:
+    """The batched hot path (pipeline.HotPath, one step over all frames of the CPU-baseline sample) against the oracle's
+    outputs for the same frames (`timed` = time_oracle's result), with the backbone convolutions in arithmetic `conv`
+    ("fp32" or "split_f16"; the split kernels are forced for every launch size so that the whole sample goes through them)."""
+    lab = pipeline.load_labels()
+    hm = pipeline.hand_model_from_labels(lab)
+    eng = _native.HipEngine(sd_np, device)
+    try:
+        eng.set_conv_arithmetic("fp32" if conv == "fp32" else "split_f16_always")
+        plan = pipeline.crop_plan_from_labels(lab, hm, timed["frame_ids"])
+        batch = pipeline.make_batch(plan, torch.from_numpy(timed["frames"].reshape(-1, 480, 636)), device)
+        hot = pipeline.HotPath(eng, hm, known_skeleton=True, keep_crops=True)
+        rec = hot.step(batch).cpu().numpy()
+        hot.check()
+        crops = hot._bufs[1].cpu().numpy()
+    finally:
+        eng.close()
+    ref = timed["oracle"]
+    return {
+        "conv_arithmetic": conv, "hand_frames": int(rec.shape[0]),
+        "crop_mismatch_fraction": float((crops != ref["crops"]).mean()),
+        "max_joint_angle_err_rad": float(np.abs(rec[:, :22] - ref["joint_angles"]).max()),
+        "max_keypoint_err_mm": float(np.linalg.norm(rec[:, 60:].reshape(-1, 21, 3) - ref["keypoints_mm"], axis=-1).max()),
+        "mean_keypoint_err_mm": float(np.linalg.norm(rec[:, 60:].reshape(-1, 21, 3) - ref["keypoints_mm"], axis=-1).mean()),
+    }
 
 
 # ----------------------------------------------------------------------------- recording_00 as a sequence
