@@ -261,11 +261,12 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
 #define SP_SLOT(CUR, NXT, N, FIRST)                                                                  \
   {                                                                                                  \
     if constexpr (FIRST && (N) == ARR) {                                                             \
-      /* my pieces of the NEXT chunk have landed (the youngest batch may stay in flight; after an epilogue the stores \
-         complete out of order with the transfers, so everything is awaited), my reads of THIS chunk are done */ \
-      if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    \
+      /* my pieces of the NEXT chunk have landed (the youngest batch may stay in flight), my reads of THIS chunk are  \
+         done.  The two arrivals after an epilogue need no wait: the epilogue's residual loads were awaited in issue \
+         order, i.e. behind every transfer issued before them, and a counted wait here would also wait for the tile's \
+         stores (vmcnt counts them, and they complete out of order with the transfers) */            \
+      if (skip_waits > 0) --skip_waits;                                                              \
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP + AP) : "memory");                            \
-      drain = false;                                                                                 \
       unsigned long long keep_;                                                                      \
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0" \
                    : "=&s"(keep_) : "v"(bar_addr), "v"(1u) : "memory");                              \
@@ -278,7 +279,11 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
         if ((int)(__builtin_amdgcn_readfirstlane(seen_) - bar_target) >= 0) break;                   \
       }                                                                                              \
       /* the ticket taken at the tile's start is older than every transfer still in flight here */    \
-      if (c == 1 && tid == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(slot_addr), "v"(grid + ticket) : "memory"); \
+      if (c == 1 && tid == 0) {                                                                      \
+        int t_ = ticket;                                                                             \
+        asm volatile("" : "+v"(t_));   /* first use HERE: hoisted above the loop it would wait (vmcnt) at the tile's start */ \
+        asm volatile("ds_write_b32 %0, %1" ::"v"(slot_addr), "v"(grid + t_) : "memory");             \
+      }                                                                                              \
     }                                                                                                \
     /* transfers: piece k of the wave (weights first) at chunk slot BAR + 1 + k * PSTEP, spread over the rest of the \
        chunk - the CU's one vector-memory pipe takes 16 cycles per piece */                          \
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   SP_A_SETUP();
   SP_W_SETUP();
   unsigned a_off = 0;
-  bool drain = false;
+  int skip_waits = 0;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     SP_A_TAP();
@@ -360,41 +365,54 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
       SP_A_ADVANCE();
       SP_W_ADVANCE();
     }
-    // ---- epilogue: 1 / (weight scale) x accumulator + bias + residual, ReLU, store
+    // ---- epilogue: 1 / (weight scale) x accumulator + bias + residual, ReLU, store.  Every residual request goes out
+    // before the first store: a load issued behind a store would make the compiler wait for that store (one counter, loads
+    // and stores complete out of order with each other) - a write round trip per accumulator.
     {
       const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
       const float floor_v = p.relu ? 0.f : -__builtin_huge_valf();
+      u32x4 rr[MI][NI][4];
+      float4 bb[NI][4];
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          bb[j][g4] = *reinterpret_cast<const float4*>(p.bias + tn * BN + wn * (NI * 32) + j * 32 + 8 * g4 + 4 * fh);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = tm * BM + wm * (MI * 32) + i * 32 + fr;
+        const bool m_ok = m < M;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int n = tn * BN + wn * (NI * 32) + j * 32 + 8 * g4 + 4 * fh;
+            const unsigned off = (m_ok && n < p.cout_store) ? (unsigned)(m * p.cout_store + n) * 4u : OOB;
+            rr[i][j][g4] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0);
+          }
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int m = tm * BM + wm * (MI * 32) + i * 32 + fr;
         const bool m_ok = m < M;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-          u32x4 rr[4];
-          float4 bb[4];
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const int n = tn * BN + wn * (NI * 32) + j * 32 + 8 * g4 + 4 * fh;
-            const unsigned off = (m_ok && n < p.cout_store) ? (unsigned)(m * p.cout_store + n) * 4u : OOB;
-            rr[g4] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0);
-            bb[g4] = *reinterpret_cast<const float4*>(p.bias + n);
-          }
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
             const int n = tn * BN + wn * (NI * 32) + j * 32 + 8 * g4 + 4 * fh;
             const unsigned off = (m_ok && n < p.cout_store) ? (unsigned)(m * p.cout_store + n) * 4u : OOB;
             u32x4 pk;
-            pk.x = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 0], p.split_unscale, bb[g4].x + __uint_as_float(rr[g4].x)), floor_v));
-            pk.y = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 1], p.split_unscale, bb[g4].y + __uint_as_float(rr[g4].y)), floor_v));
-            pk.z = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 2], p.split_unscale, bb[g4].z + __uint_as_float(rr[g4].z)), floor_v));
-            pk.w = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 3], p.split_unscale, bb[g4].w + __uint_as_float(rr[g4].w)), floor_v));
+            pk.x = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 0], p.split_unscale, bb[j][g4].x + __uint_as_float(rr[i][j][g4].x)), floor_v));
+            pk.y = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 1], p.split_unscale, bb[j][g4].y + __uint_as_float(rr[i][j][g4].y)), floor_v));
+            pk.z = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 2], p.split_unscale, bb[j][g4].z + __uint_as_float(rr[i][j][g4].z)), floor_v));
+            pk.w = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 3], p.split_unscale, bb[j][g4].w + __uint_as_float(rr[i][j][g4].w)), floor_v));
             __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, off, 0, 0);
           }
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         }
       }
-      drain = true;     // stores complete out of order with the transfers: the next barrier waits for everything
+      skip_waits = 2;
     }
     if (next_tile >= n_tiles) break;
     tile = next_tile;

@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--conv", choices=["fp32", "split_f16"], default="split_f16",
                     help="arithmetic of the batched backbone convolutions (ut_set_conv_arithmetic): exact fp32 matrix "
                          "instructions, or two-piece fp16 splits of both operands on the fp16 matrix cores (fp32-level error)")
+    ap.add_argument("--no-fp32-mode", action="store_true",
+                    help="with --conv split_f16: skip the exact-fp32 timing and the record comparison against it (profiling runs)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend for N>1 (nccl = RCCL over xGMI; gloo only to rehearse the multi-process "
                          "control flow on a box with fewer GPUs than ranks: ranks then share devices)")
@@ -155,7 +157,7 @@ def main():
     # split-fp16 mode: the same K steps timed with the exact-fp32 convolutions (every rank, same barriers), and the records
     # of the timed workload against that mode's on the same batch
     split_check, fp32_mode = None, None
-    if args.conv != "fp32":
+    if args.conv != "fp32" and not args.no_fp32_mode:
         rec_split = hot.step(batch).clone()
         eng.set_conv_arithmetic("fp32")
         dt32, _ = timed_run()
@@ -188,7 +190,9 @@ def main():
         traffic, traffic_source = None, None
         prof_dir = os.path.join(ROOT, "profiles")
         cands = sorted(f for f in (os.listdir(prof_dir) if os.path.isdir(prof_dir) else []) if f.endswith("_conv_traffic.json"))
-        if cands and f_local == 1024 and known and not split_kind:
+        cands = [f for f in cands
+                 if json.load(open(os.path.join(prof_dir, f))).get("conv_arithmetic", "fp32") == ("split_f16" if split_kind else "fp32")]
+        if cands and f_local == 1024 and known:
             tj = json.load(open(os.path.join(prof_dir, cands[-1])))
             traffic = tj.get("traffic_bytes_per_launch")
             traffic_source = (f"profiles/{cands[-1]}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `{tj.get('label', '')}` "

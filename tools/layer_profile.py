@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-layer view of a rocprofv3 --kernel-trace CSV of `bench.py` (known-skeleton mode):
-maps the conv_igemm launches of the LAST step to the network's convolutions by launch order and
+maps the convolution launches (conv_igemm / conv_split / halo patch) of the LAST step to the network's convolutions by launch order and
 prints duration, FLOPs and TFLOP/s of each, plus totals of every other kernel in that step.
     python tools/layer_profile.py <kernel_trace.csv> <n_crops> <chunk>"""
 import collections
@@ -42,18 +42,29 @@ head = [("fus0 144->108", 144 * 108), ("fus1 108->72", 108 * 72), ("fus2 72->72"
         ("reg1.conv1 76", 9 * 76 * 76), ("reg1.conv2 76", 9 * 76 * 76)]
 seq += [(nm, 2 * mac * 36 * s) for nm, mac in head]
 
-is_conv = lambda r: "conv_igemm" in r["Kernel_Name"] or "conv3x3_c32_patch" in r["Kernel_Name"]
+is_conv = lambda r: any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_c32_patch", "conv_split"))
+
+
+def label(name):
+    args = name.split("<")[1].split(">")[0] if "<" in name else ""
+    if "conv_split" in name:
+        return "split f16 " + "x".join(args.split(", ")[:2])
+    if "conv3x3_c32_patch" in name:
+        return "halo patch 16x24" + (" split f16" if args == "true" else "")
+    return "fp32 " + "x".join(args.split(", ")[:2])
+
+
 convs = [r for r in rows if is_conv(r)]
 last = convs[-len(seq):]
 agg = collections.OrderedDict()
 for (nm, fl), r in zip(seq, last):
-    tile = r["Kernel_Name"].split("<")[1].split(">")[0] if "<" in r["Kernel_Name"] else "halo patch 16x24"
+    tile = label(r["Kernel_Name"])
     a = agg.setdefault(nm, [0, 0.0, 0.0, tile])
     a[0] += 1; a[1] += dur(r); a[2] += fl
 tot_t = sum(a[1] for a in agg.values()); tot_f = sum(a[2] for a in agg.values())
-print(f"{'conv':28s} {'tile':16s} {'n':>3s} {'total us':>10s} {'TFLOP/s':>8s} {'% of conv time':>8s}")
+print(f"{'conv':28s} {'kernel':26s} {'n':>3s} {'total us':>10s} {'TFLOP/s':>8s} {'% of conv time':>8s}")
 for nm, (n, t, fl, tile) in agg.items():
-    print(f"{nm:28s} {tile:16s} {n:3d} {t:10.1f} {fl/t/1e6:8.1f} {100*t/tot_t:8.2f}")
+    print(f"{nm:28s} {tile:26s} {n:3d} {t:10.1f} {fl/t/1e6:8.1f} {100*t/tot_t:8.2f}")
 print(f"conv total {tot_t/1e3:.3f} ms, {tot_f/tot_t/1e6:.1f} TFLOP/s")
 t0 = int(last[0]["Start_Timestamp"])
 others = collections.Counter()

@@ -3,7 +3,9 @@
 a pass on gfx950: MI355X_MICROARCH.md "rocprofv3 PMC slots").  Corrections per that guide's HBM section:
 counters are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a wide (16 B/lane) coalesced read, so it is
 doubled; WRITE_SIZE is exact for 16 B/lane stores.
-    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [label] [n_steps]
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [label] [n_steps] [fp32|split_f16]
+The last argument names the arithmetic the profiled command ran (ut_set_conv_arithmetic): the per-launch figure is over the
+kernels bench.py's roofline object covers in that mode.
 With n_steps (hot-path steps the profiled command ran, warm-up included) the summary also holds the HBM bytes of one
 whole step over ALL of the library's kernels (resampler, stem, convolutions, head glue, FK) and their ratio to the
 algorithmic bytes of SURVEY.md 8(d) (2048 hand-frames x 74,220 B)."""
@@ -12,10 +14,19 @@ import json
 import sys
 
 
+KIND = sys.argv[6] if len(sys.argv) > 6 else "fp32"
+
+
+def covered(name):
+    if KIND == "split_f16":
+        return "conv_split_kernel" in name or "conv3x3_c32_patch_kernel<true>" in name
+    return "conv_igemm" in name or "conv3x3_c32_patch" in name
+
+
 def per_launch(path, counter):
     tot, n = 0.0, 0
     for r in csv.DictReader(open(path)):
-        if ("conv_igemm" in r["Kernel_Name"] or "conv3x3_c32_patch" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
+        if covered(r["Kernel_Name"]) and r["Counter_Name"] == counter:
             tot += float(r["Counter_Value"])
             n += 1
     return tot, n
@@ -34,7 +45,9 @@ def per_kernel(path, counter):
 fetch, nf = per_launch(sys.argv[1], "FETCH_SIZE")
 write, nw = per_launch(sys.argv[2], "WRITE_SIZE")
 out = {
-    "kernel": "conv_igemm_kernel (all instantiations) + conv3x3_c32_patch_kernel", "label": sys.argv[4] if len(sys.argv) > 4 else "",
+    "conv_arithmetic": KIND,
+    "kernel": ("conv_split_kernel (both instantiations) + conv3x3_c32_patch_kernel<true>" if KIND == "split_f16" else
+               "conv_igemm_kernel (all instantiations) + conv3x3_c32_patch_kernel"), "label": sys.argv[4] if len(sys.argv) > 4 else "",
     "launches_fetch_pass": nf, "launches_write_pass": nw,
     "FETCH_SIZE_KiB_per_launch_raw": fetch / max(nf, 1), "WRITE_SIZE_KiB_per_launch": write / max(nw, 1),
     "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE counts 64 B per 128-B request)",
