@@ -37,7 +37,7 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"]
         if r["Counter_Name"] == counter and ("ut::" in k):
-            name = k.split("(")[0].replace("void ", "")
+            name = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
             tot[name] = tot.get(name, 0.0) + float(r["Counter_Value"])
     return tot
 
