@@ -58,7 +58,7 @@ def oracle_frames(sd_np, lab, hm_np, frame_ids, frames_u8: np.ndarray, known: bo
             "hand_idx": hand_idx, "skel_scales": None if o["skel_scales"] is None else o["skel_scales"].numpy()}
 
 
-def run_small_end_to_end(sd_np, n_frames: int = 2, device: str = "cuda:0", known: bool = True) -> Dict[str, float]:
+def run_small_end_to_end(sd_np, n_frames: int = 2, device: str = "cuda:0", known: bool = True, conv: str = "fp32") -> Dict[str, float]:
     lab = pipeline.load_labels()
     hm = pipeline.hand_model_from_labels(lab)
     hm_np = {k[3:]: v for k, v in lab.items() if k.startswith("hm.")}
@@ -66,6 +66,7 @@ def run_small_end_to_end(sd_np, n_frames: int = 2, device: str = "cuda:0", known
     frames = synth.synthetic_frames(n_frames, seed=5)
     eng = _native.HipEngine(sd_np, device)
     try:
+        eng.set_conv_arithmetic(conv)        # "split_f16_always": the split-fp16 kernels also for this handful of crops
         plan = pipeline.crop_plan_from_labels(lab, hm, frame_ids)
         batch = pipeline.make_batch(plan, torch.from_numpy(frames.reshape(-1, 480, 636)), device)
         hot = pipeline.HotPath(eng, hm, known_skeleton=known, keep_crops=True)

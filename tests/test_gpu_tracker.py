@@ -166,9 +166,12 @@ def test_skin_landmarks_shim_leading_dims(labels, hand_model):
     assert one.device.type == "cuda" and np.abs(one.cpu().numpy() - want[2, 1]).max() < 2e-4
 
 
+@pytest.mark.parametrize("conv", ["fp32", "split_f16_always"])
 @pytest.mark.parametrize("known", [True, False])
-def test_batched_hot_path_vs_oracle(known):
-    r = checks.run_small_end_to_end(synth.synthetic_state_dict(0), n_frames=3, device=DEV, known=known)
+def test_batched_hot_path_vs_oracle(known, conv):
+    """resample -> backbone -> head -> FK in one batched step against the oracle on the same crops, with the backbone's 3x3
+    convolutions on the exact fp32 matrix instruction and on the split-fp16 kernels: the same tolerances (north_star)."""
+    r = checks.run_small_end_to_end(synth.synthetic_state_dict(0), n_frames=3, device=DEV, known=known, conv=conv)
     assert r["hand_frames"] == 6
     assert r["crop_mismatch_fraction"] < 2e-3 and r["crop_max_abs_diff"] <= 8.0 / 255.0
     assert r["max_joint_angle_err_rad"] < 1e-4
