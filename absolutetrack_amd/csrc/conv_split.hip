@@ -90,17 +90,26 @@ __device__ __forceinline__ f16x8 frag(const unsigned (&v)[4]) {
   return __builtin_bit_cast(f16x8, t);
 }
 
-template <int BM, int BN, int WR, int WC>
+// HALO (stride-1 3x3 convolutions from 64 input channels): the pixels of a 32-channel slice are not gathered tap by tap;
+// the tile's input rows - 256 consecutive pixels plus one image row and one pixel on either side, a CONTIGUOUS range of
+// the [pixel][channel] matrix - are brought into LDS once per slice (two buffers) and the nine taps read shifted rows of
+// that patch, with a per-pixel 9-bit validity mask pointing out-of-image taps at a row of zeros.  Per chunk the
+// workgroup then fetches 4.4 KB of pixels instead of 32.
+template <int BM, int BN, int WR, int WC, bool HALO>
 __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int tiles_n, int n_tiles) {
   static_assert(WR * WC == 8, "8 waves per workgroup");
   constexpr int MI = BM / WR / 32, NI = BN / WC / 32;
   constexpr int AP = BM / 64;              // pixel pieces per wave per chunk (a piece = 8 rows x 128 B)
   constexpr int WTOT = BN / 32 * 4;        // 1-KB weight blocks per chunk: (32 rows) x (k-step) x (plane)
   constexpr int WP = (WTOT + 7) / 8;       // ... per wave
-  constexpr int A_STAGE = BM * 128, W_STAGE = BN * 128;
-  constexpr int A_RING = 3, W_RING = 3;
+  constexpr int HROWS = 320;               // HALO: patch rows per slice (256 + 2 * (image width + 1) <= 320: width <= 31)
+  constexpr int NPH = HROWS / 64;          // ... 1-KB pieces per wave
+  constexpr int A_STAGE = HALO ? HROWS * 128 : BM * 128, W_STAGE = BN * 128;
+  constexpr int A_RING = HALO ? 2 : 3, W_RING = 3;
   constexpr int W_BASE = A_RING * A_STAGE;
-  constexpr int SLOT = W_BASE + W_RING * W_STAGE;
+  constexpr int ZROW = W_BASE + W_RING * W_STAGE;          // 128 bytes of zeros (HALO: the target of out-of-image taps)
+  constexpr int SLOT = ZROW + 128;
+  constexpr unsigned HOOB = 0x80000000u;   // out-of-range offset that stays out of range with a slice offset added
   constexpr int NM = 3 * MI * NI;          // MFMAs (= slots) per k-step; a chunk has 2 * NM
   constexpr int UNITS = MI * 4;            // pair conversions per k-step, one per slot from CV0
   constexpr int NWF = NI * 2;              // weight-fragment reads per k-step, one per slot from RD0
@@ -108,10 +117,11 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   constexpr int CV0 = NM >= 12 ? 4 : 2;
   constexpr int ARR = RD0 + NWF + (NM >= 12 ? 2 : 0);   // slot of the arrival: behind the chunk's last fragment read
   constexpr int BAR = ARR + 1;                           // slot of the wait; the transfers follow it
-  constexpr int PSTEP = (2 * NM - BAR - 2) / (WP + AP);  // slots between two transfers of a wave
+  constexpr int NPC = HALO ? WP + 1 : WP + AP;           // transfers of a wave per chunk
+  constexpr int PSTEP = (2 * NM - BAR - 2) / NPC;        // slots between two transfers of a wave
   constexpr int ASEP = PSTEP >= 2 ? 1 : 0;               // a pixel piece's offset arithmetic one slot ahead of its transfer
   static_assert(ARR < NM && BAR < NM && CV0 + UNITS <= NM, "arrival, wait and conversions inside the first k-step");
-  static_assert(PSTEP >= 1 && BAR + 1 + (WP + AP - 1) * PSTEP + ASEP < 2 * NM, "room for the transfers");
+  static_assert(PSTEP >= 1 && BAR + 1 + (NPC - 1) * PSTEP + ASEP < 2 * NM, "room for the transfers");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -153,6 +163,48 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   unsigned fw_row;                                            // byte offset of (tile column, chunk 0) of this wave's first block
   const unsigned w_lane = (unsigned)lane * 16u;
   int next_tile = 0;                                          // the tile after the one being computed (valid once read)
+
+  // ---- HALO: patch stream (one slice ahead of the MFMAs) and the read side's row arithmetic
+  const int n_slices = p.cin / 32;
+  const int wimg = p.W;
+  unsigned h_off[NPH];          // per-lane byte offset of this wave's pieces of the fetch tile's patch (slice 0)
+  unsigned h_buf = 0;           // byte offset of the patch buffer being filled
+  int c_tap = 0, c_slice = 0;   // tap and slice of the chunk being computed
+  unsigned c_buf = 0;           // ... and its patch buffer
+  int r_tap = 0;                // tap of the chunk the fragment reads are at (one k-step ahead of the MFMAs)
+  unsigned r_buf = 0;
+  unsigned rmask[MI];           // 9 validity bits (tap order) of the lane's pixel in fragment i of the tile being read
+  int lrow[MI];                 // its row in the patch for the centre tap
+#pragma unroll
+  for (int i = 0; i < MI; ++i) { lrow[i] = wm * (MI * 32) + i * 32 + fr + wimg + 1; rmask[i] = 0; }
+#define SP_H_SETUP(TILE)                                                                             \
+  {                                                                                                  \
+    const int g0_ = ((TILE) / tiles_n) * BM - wimg - 1;                                              \
+    _Pragma("unroll") for (int q = 0; q < NPH; ++q) {                                                \
+      const int row_ = 8 * (wave + 8 * q) + (lane >> 3);                                             \
+      const int pix_ = g0_ + row_;                                                                   \
+      const bool ok_ = pix_ >= 0 && pix_ < M && (TILE) < n_tiles;                                    \
+      h_off[q] = ok_ ? (unsigned)(pix_ * p.cin + 4 * ((lane & 7) ^ ((row_ >> 1) & 7))) * 4u : HOOB;  \
+    }                                                                                                \
+  }
+#define SP_H_ISSUE(Q, SLICE) dma_piece(a_words, smem_addr + h_buf + (unsigned)((wave + 8 * (Q)) * 1024), h_off[Q], (unsigned)(SLICE) * 128u)
+#define SP_H_MASK(TILE)                                                                              \
+  {                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                 \
+      const int m_ = ((TILE) / tiles_n) * BM + wm * (MI * 32) + i * 32 + fr;                         \
+      const bool in_ = m_ < M && (TILE) < n_tiles;                                                   \
+      const int mm_ = in_ ? m_ : 0;                                                                  \
+      const int img_ = fdiv(mm_, hw, inv_hw);                                                        \
+      const int rem_ = mm_ - img_ * hw;                                                              \
+      const int y_ = fdiv(rem_, wimg, inv_wo), x_ = rem_ - y_ * wimg;                                \
+      unsigned mk_ = 0;                                                                              \
+      _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                \
+        const bool ok_ = (unsigned)(y_ + t / 3 - 1) < (unsigned)p.H && (unsigned)(x_ + t % 3 - 1) < (unsigned)wimg; \
+        mk_ |= (ok_ ? 1u : 0u) << t;                                                                 \
+      }                                                                                              \
+      rmask[i] = in_ ? mk_ : 0u;                                                                     \
+    }                                                                                                \
+  }
 
 #define SP_A_SETUP()                                                                                 \
   {                                                                                                  \
@@ -229,9 +281,21 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   }
 #define SP_READ_X(S, A_ST)                                                                           \
   {                                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
-      _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                  \
-        xr[i][h] = *reinterpret_cast<const float4*>(smem + (A_ST) + x_row + i * 4096 + x_pos[S][h]); \
+    if constexpr (HALO) {     /* row of the patch for tap r_tap, or the row of zeros */              \
+      const int dy_ = (r_tap * 11) >> 5, dx_ = r_tap - 3 * dy_;                                      \
+      const int sh_ = (dy_ - 1) * wimg + dx_ - 1;                                                    \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                               \
+        const int row_ = lrow[i] + sh_;                                                              \
+        const unsigned a_ = r_buf + (unsigned)(row_ * 128) + (unsigned)((((4 * (S) + 2 * fh) ^ ((row_ >> 1) & 7))) << 4); \
+        const unsigned a0_ = ((rmask[i] >> r_tap) & 1u) ? a_ : (unsigned)ZROW;                       \
+        xr[i][0] = *reinterpret_cast<const float4*>(smem + a0_);                                     \
+        xr[i][1] = *reinterpret_cast<const float4*>(smem + (a0_ ^ 16u));                             \
+      }                                                                                              \
+    } else {                                                                                         \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                \
+          xr[i][h] = *reinterpret_cast<const float4*>(smem + (A_ST) + x_row + i * 4096 + x_pos[S][h]); \
+    }                                                                                                \
   }
 #define SP_READ_WALL(SET, S)                                                                         \
   {                                                                                                  \
@@ -266,7 +330,9 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
          order, i.e. behind every transfer issued before them, and a counted wait here would also wait for the tile's \
          stores (vmcnt counts them, and they complete out of order with the transfers) */            \
       if (skip_waits > 0) --skip_waits;                                                              \
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP + AP) : "memory");                            \
+      else if constexpr (!HALO) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP + AP) : "memory");       \
+      else if (prev_had_patch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP + 1) : "memory");         \
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP) : "memory");                                 \
       unsigned long long keep_;                                                                      \
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0" \
                    : "=&s"(keep_) : "v"(bar_addr), "v"(1u) : "memory");                              \
@@ -289,9 +355,16 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
        chunk - the CU's one vector-memory pipe takes 16 cycles per piece */                          \
     constexpr int g_ = (FIRST ? 0 : NM) + (N) - BAR - 1;                                             \
     if constexpr (g_ >= 0 && g_ % PSTEP == 0 && g_ / PSTEP < WP) SP_W_ISSUE(g_ / PSTEP);              \
-    if constexpr (g_ >= 0 && g_ % PSTEP == 0 && g_ / PSTEP >= WP && g_ / PSTEP < WP + AP) SP_A_ADDR(g_ / PSTEP - WP, a_off); \
-    if constexpr (g_ >= ASEP && (g_ - ASEP) % PSTEP == 0 && (g_ - ASEP) / PSTEP >= WP && (g_ - ASEP) / PSTEP < WP + AP) \
+    if constexpr (!HALO && g_ >= 0 && g_ % PSTEP == 0 && g_ / PSTEP >= WP && g_ / PSTEP < WP + AP) SP_A_ADDR(g_ / PSTEP - WP, a_off); \
+    if constexpr (!HALO && g_ >= ASEP && (g_ - ASEP) % PSTEP == 0 && (g_ - ASEP) / PSTEP >= WP && (g_ - ASEP) / PSTEP < WP + AP) \
       SP_A_ISSUE((g_ - ASEP) / PSTEP - WP, a_off);                                                   \
+    if constexpr (HALO && g_ == WP * PSTEP) {      /* one piece of the next slice's patch in the slice's first NPH chunks */ \
+      if (c_tap == 0) SP_H_ISSUE(0, f_slice);                                                        \
+      else if (c_tap == 1) SP_H_ISSUE(1, f_slice);                                                   \
+      else if (c_tap == 2) SP_H_ISSUE(2, f_slice);                                                   \
+      else if (c_tap == 3) SP_H_ISSUE(3, f_slice);                                                   \
+      else if (c_tap == 4) SP_H_ISSUE(4, f_slice);                                                   \
+    }                                                                                                \
     if constexpr ((N) >= CV0 && (N) - CV0 < UNITS) SP_CONV(NXT, (N) - CV0);                          \
     if constexpr ((N) >= RD0 && (N) - RD0 < NWF) SP_READ_W1(NXT, FIRST ? 1 : 0, (N) - RD0);          \
     SP_PIN();                                                                                        \
@@ -305,27 +378,40 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
     if constexpr (NM > 6) { SP_SLOTS3(CUR, NXT, 6, FIRST) SP_SLOTS3(CUR, NXT, 9, FIRST) }            \
   }
   static_assert(NM == 6 || NM == 12, "SP_STEP expands 6 or 12 slots");
+  static_assert(NPH == 5, "SP_SLOT issues patch pieces 0..4");
 
   const unsigned slot_addr = smem_addr + (unsigned)SLOT;
   const unsigned bar_addr = slot_addr + 4;     // arrivals of the split chunk barrier (monotonic)
   unsigned bar_target = 0;
   if (tid == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(bar_addr), "v"(0u) : "memory");
-  // ---- prologue: chunks 0, 1 and 2 of the first tile
-  SP_A_SETUP();
+  // ---- prologue: chunks 0, 1 and 2 of the first tile (HALO: the patch of its first slice and three weight chunks)
+  if constexpr (!HALO) SP_A_SETUP();
   SP_W_SETUP();
   unsigned a_off = 0;
   int skip_waits = 0;
+  bool prev_had_patch = false;
+  int f_slice = 0;              // HALO: slice of the patch being fetched
+  if (lane < 8 && wave == 0) asm volatile("ds_write_b128 %0, %1" ::"v"(smem_addr + (unsigned)ZROW + (unsigned)lane * 16u), "v"(u32x4{0, 0, 0, 0}) : "memory");
+  if constexpr (HALO) {
+    SP_H_SETUP(slot);
+    SP_H_MASK(slot);
+    SP_H_ISSUE(0, 0); SP_H_ISSUE(1, 0); SP_H_ISSUE(2, 0); SP_H_ISSUE(3, 0); SP_H_ISSUE(4, 0);
+    h_buf = A_STAGE;
+    f_slice = n_slices > 1 ? 1 : 0;
+  }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    SP_A_TAP();
+    if constexpr (!HALO) {
+      SP_A_TAP();
 #pragma unroll
-    for (int i = 0; i < AP; ++i) { SP_A_ADDR(i, a_off); SP_A_ISSUE(i, a_off); }
-    SP_A_ADVANCE();
+      for (int i = 0; i < AP; ++i) { SP_A_ADDR(i, a_off); SP_A_ISSUE(i, a_off); }
+      SP_A_ADVANCE();
+    }
 #pragma unroll
     for (int t = 0; t < WP; ++t) SP_W_ISSUE(t);
     SP_W_ADVANCE();
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -343,26 +429,52 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
     const int ticket = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, q_rsrc, q_off, 0, 0);
     for (int c = 0; c < n_chunks; ++c) {
       // tile hand-over of the fetch streams: they enter the next tile three chunks before the MFMAs do (the queue slot
-      // was written during chunk 1 and published by the synchronisations since)
-      if (c == n_chunks - 3) {
+      // was written during chunk 1 and published by the synchronisations since); HALO: the patch stream enters it with
+      // the tile's last slice, nine chunks ahead
+      if (c == n_chunks - (HALO ? 9 : 3)) {
         int nv;
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nv) : "v"(slot_addr) : "memory");
         next_tile = __builtin_amdgcn_readfirstlane(nv);
-        fa_tile = next_tile;
-        SP_A_SETUP();
+        if constexpr (HALO) {
+          SP_H_SETUP(next_tile);
+          f_slice = 0;
+        } else {
+          fa_tile = next_tile;
+          SP_A_SETUP();
+        }
+      }
+      if (c == n_chunks - 3) {
         fw_tile = next_tile;
         SP_W_SETUP();
       }
-      SP_A_TAP();
+      if constexpr (!HALO) SP_A_TAP();
       // first k-step: set 0; its slot 0 reads the second k-step of the same chunk into set 1
       SP_READ_X(1, rd_a);
       SP_STEP(0, 1, true)
       // second k-step: set 1; reads the first k-step of the next chunk (published by this chunk's barrier) into set 0
       rd_a = rd_a + A_STAGE == A_RING * A_STAGE ? 0u : rd_a + A_STAGE;
       rd_w = rd_w + W_STAGE == W_RING * W_STAGE ? 0u : rd_w + W_STAGE;
+      if constexpr (HALO) {     // the read side moves to the next chunk: next tap, or the next slice's patch buffer
+        if (++r_tap == 9) {
+          r_tap = 0;
+          r_buf ^= (unsigned)A_STAGE;
+          if (c == n_chunks - 1) SP_H_MASK(next_tile);
+        }
+      }
       SP_READ_X(0, rd_a);
       SP_STEP(1, 0, false)
-      SP_A_ADVANCE();
+      if constexpr (HALO) {
+        prev_had_patch = c_tap < NPH;
+        if (++c_tap == 9) {     // the MFMAs move to the next slice: the buffer they leave takes the patch after next
+          c_tap = 0;
+          h_buf ^= (unsigned)A_STAGE;
+          ++c_slice;
+          if (c_slice == n_slices) c_slice = 0;
+          f_slice = c_slice + 1 < n_slices ? c_slice + 1 : 0;
+        }
+      } else {
+        SP_A_ADVANCE();
+      }
       SP_W_ADVANCE();
     }
     // ---- epilogue: 1 / (weight scale) x accumulator + bias + residual, ReLU, store.  Every residual request goes out
@@ -418,6 +530,9 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
     tile = next_tile;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the transfers issued for tiles that do not exist
+#undef SP_H_SETUP
+#undef SP_H_ISSUE
+#undef SP_H_MASK
 #undef SP_A_SETUP
 #undef SP_W_SETUP
 #undef SP_A_TAP
@@ -437,24 +552,24 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
 #undef SP_STEP
 }
 
-template <int BM, int BN, int WR, int WC>
+template <int BM, int BN, int WR, int WC, bool HALO>
 hipError_t launch_split_cfg(const ConvLaunch& c, hipStream_t s) {
   const int M = c.n_img * c.Ho * c.Wo;
   const int tiles_m = (M + BM - 1) / BM;
   const int tiles_n = (c.cout_store + BN - 1) / BN;
   const int n_tiles = tiles_m * tiles_n;
-  const size_t lds = 3 * (size_t)BM * 128 + 3 * (size_t)BN * 128 + 16;
+  const size_t lds = (HALO ? 2 * (size_t)320 * 128 : 3 * (size_t)BM * 128) + 3 * (size_t)BN * 128 + 128 + 16;
   static std::atomic<unsigned long long> attr_set{0};
   const unsigned long long dev_bit = (c.device >= 0 && c.device < 64) ? 1ull << c.device : 0ull;
   if (!(attr_set.load(std::memory_order_relaxed) & dev_bit) || !dev_bit) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<BM, BN, WR, WC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<BM, BN, WR, WC, HALO>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set.fetch_or(dev_bit, std::memory_order_relaxed);
   }
   int grid = c.num_cu;
   if (grid > n_tiles) grid = n_tiles;
-  hipLaunchKernelGGL((conv_split_kernel<BM, BN, WR, WC>), dim3(grid), dim3(512), lds, s, c, tiles_n, n_tiles);
+  hipLaunchKernelGGL((conv_split_kernel<BM, BN, WR, WC, HALO>), dim3(grid), dim3(512), lds, s, c, tiles_n, n_tiles);
   return hipGetLastError();
 }
 
@@ -469,8 +584,10 @@ hipError_t launch_conv_split(const ConvLaunch& c, hipStream_t s) {
   if (!conv_split_applicable(c)) return hipErrorInvalidValue;
   if ((size_t)c.n_img * c.H * c.W * c.cin * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
   if ((size_t)c.n_img * c.Ho * c.Wo * c.cout_store * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
-  if (c.cout_store <= 64) return launch_split_cfg<256, 64, 8, 1>(c, s);
-  return launch_split_cfg<256, 128, 4, 2>(c, s);
+  // stride-1 3x3 from 64 input channels up (image rows of at most 31 pixels): the input halo resident in LDS
+  const bool halo = c.ksize == 3 && c.stride == 1 && c.pad == 1 && c.cin >= 64 && c.W <= 31 && c.H == c.Ho && c.W == c.Wo;
+  if (c.cout_store <= 64) return halo ? launch_split_cfg<256, 64, 8, 1, true>(c, s) : launch_split_cfg<256, 64, 8, 1, false>(c, s);
+  return halo ? launch_split_cfg<256, 128, 4, 2, true>(c, s) : launch_split_cfg<256, 128, 4, 2, false>(c, s);
 }
 
 // Host side: the two fp16 planes of the packed fp32 weights [cout_pad][k_pad], pre-scaled by `scale` (a power of two),

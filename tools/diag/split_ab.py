@@ -22,10 +22,13 @@ VARIANTS = {
     "noconv": [("  const f16x2 h = ", "  p0 = __float_as_uint(a); p1 = __float_as_uint(b); return;\n  const f16x2 h = ")],
     # no transfers after the prologue (stale operands): what the fetch costs
     "nodma": [("#define SP_A_ISSUE(I, OFF) dma_piece(", "#define SP_A_ISSUE(I, OFF) if (p.k_pad < 0) dma_piece("),
+              ("#define SP_H_ISSUE(Q, SLICE) dma_piece(", "#define SP_H_ISSUE(Q, SLICE) if (p.k_pad < 0) dma_piece("),
               ("    dma_piece(w_words, smem_addr + W_BASE + fw_stage", "    if (p.k_pad < 0) dma_piece(w_words, smem_addr + W_BASE + fw_stage")],
-    # no residual loads and no stores
-    "noepi": [("            __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, off, 0, 0);", "            if (p.k_pad < 0 || (pk.x == 0x12345678u && tid == 99999)) __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, off, 0, 0);"),
-              ("            rr[g4] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0);", "            rr[g4] = u32x4{0, 0, 0, 0};")],
+    # no chunk synchronisation (racy: timing only)
+    "nosync": [("      asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_mov_b64 %0, exec", "      if (p.k_pad < 0) asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_mov_b64 %0, exec"),
+               ("      for (;;) {                                                                                     \\", "      for (; p.k_pad < 0;) {                                                                         \\")],
+    # no counted vmcnt wait at the arrival (racy: timing only)
+    "nowait": [("      if (skip_waits > 0) --skip_waits;  ", "      if (p.k_pad >= 0) {} else if (skip_waits > 0) --skip_waits;  ")],
 }
 variants = [v for v in os.environ.get("SPLIT_VARIANTS", "").split(",") if v]
 
