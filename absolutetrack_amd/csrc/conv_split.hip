@@ -43,6 +43,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) unsigned lds_u32;
 
 constexpr unsigned OOB = 0xFFFFFF00u;
 
@@ -115,13 +116,22 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   constexpr int NWF = NI * 2;              // weight-fragment reads per k-step, one per slot from RD0
   constexpr int RD0 = NM >= 12 ? 2 : 0;
   constexpr int CV0 = NM >= 12 ? 4 : 2;
-  constexpr int ARR = RD0 + NWF + (NM >= 12 ? 2 : 0);   // slot of the arrival: behind the chunk's last fragment read
-  constexpr int BAR = ARR + 1;                           // slot of the wait; the transfers follow it
+  // Chunk synchronisation through two LDS counters, each signalled long before it is waited for (with one workgroup
+  // per CU nothing hides an s_barrier's turn-around; with the two halves 1-2 slots apart it still cost 18 %):
+  //   LANDED  signalled at slot 0 of the chunk: my pieces of the NEXT chunk are in LDS (counted vmcnt);
+  //           awaited before the first read of the next chunk (start of the second k-step).
+  //   READ    signalled at slot ARR: my fragment reads of THIS chunk are done;
+  //           awaited at chunk slot RW, in front of my first transfer into the buffers this chunk frees.
+  constexpr int ARR = RD0 + NWF + (NM >= 12 ? 4 : 0);   // well behind the chunk's last fragment read (its lgkmcnt(0) should not stall)
+  constexpr int RW = NM + (NM >= 12 ? 1 : 0);            // chunk slot (second k-step) of the READ wait
+  constexpr int PS0 = RW + 1;                            // chunk slot of the wave's first transfer
+  constexpr int PEEK = NM >= 12 ? 3 : 2;                 // slots between the look at a counter and its use
+  static_assert(RW - PEEK >= ARR && NM - PEEK > 0, "the counters are looked at after the wave's own signal");
   constexpr int NPC = HALO ? WP + 1 : WP + AP;           // transfers of a wave per chunk
-  constexpr int PSTEP = (2 * NM - BAR - 2) / NPC;        // slots between two transfers of a wave
+  constexpr int PSTEP = (2 * NM - PS0) / NPC;            // slots between two transfers of a wave
   constexpr int ASEP = PSTEP >= 2 ? 1 : 0;               // a pixel piece's offset arithmetic one slot ahead of its transfer
-  static_assert(ARR < NM && BAR < NM && CV0 + UNITS <= NM, "arrival, wait and conversions inside the first k-step");
-  static_assert(PSTEP >= 1 && BAR + 1 + (NPC - 1) * PSTEP + ASEP < 2 * NM, "room for the transfers");
+  static_assert(ARR < NM && CV0 + UNITS <= NM, "READ signal and conversions inside the first k-step");
+  static_assert(PSTEP >= 1 && PS0 + (NPC - 1) * PSTEP + ASEP < 2 * NM, "room for the transfers");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -320,30 +330,46 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
     acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(wf[SET][j_][wp_]), frag(xp[SET][i_][xp_]), acc[i_][j_], 0, 0, 0); \
   }
 
+#define SP_SIGNAL(ADDR, LGKM)                                                                         \
+  {                                                                                                  \
+    unsigned long long keep_;                                                                        \
+    if constexpr (LGKM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                           \
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0" \
+                 : "=&s"(keep_) : "v"(ADDR), "v"(1u) : "memory");                                    \
+  }
+  /* a counter is LOOKED AT a few MFMA slots before it is needed (a plain LDS load: the compiler places the wait at its
+     first use), so that the common case costs no LDS round trip in front of the MFMAs; only a value that is still short
+     falls into the polling loop */                                                                   \
+#define SP_PEEK(ADDR) (*reinterpret_cast<volatile lds_u32*>(ADDR))
+#define SP_AWAIT(PEEKED, ADDR, TARGET)                                                               \
+  if ((int)(__builtin_amdgcn_readfirstlane(PEEKED) - (TARGET)) < 0) {                                \
+    for (;;) {                                                                                       \
+      unsigned seen_;                                                                                \
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen_) : "v"(ADDR) : "memory"); \
+      if ((int)(__builtin_amdgcn_readfirstlane(seen_) - (TARGET)) >= 0) break;                       \
+    }                                                                                                \
+  }
   // One MFMA slot of a k-step.  CUR: register set consumed, NXT: set filled for the following step.  FIRST: the chunk's
   // first step, which carries the arrival and the wait of the chunk's synchronisation.
 #define SP_SLOT(CUR, NXT, N, FIRST)                                                                  \
   {                                                                                                  \
-    if constexpr (FIRST && (N) == ARR) {                                                             \
-      /* my pieces of the NEXT chunk have landed (the youngest batch may stay in flight), my reads of THIS chunk are  \
-         done.  The two arrivals after an epilogue need no wait: the epilogue's residual loads were awaited in issue \
-         order, i.e. behind every transfer issued before them, and a counted wait here would also wait for the tile's \
-         stores (vmcnt counts them, and they complete out of order with the transfers) */            \
+    if constexpr (FIRST && (N) == 0) {                                                               \
+      /* LANDED: my pieces of the next chunk are in LDS (the youngest batch may stay in flight).  The two chunks after \
+         an epilogue need no wait: the epilogue's residual loads were awaited in issue order, i.e. behind every      \
+         transfer issued before them, and a counted wait here would also wait for the tile's stores (vmcnt counts    \
+         them, and they complete out of order with the transfers) */                                  \
       if (skip_waits > 0) --skip_waits;                                                              \
       else if constexpr (!HALO) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP + AP) : "memory");       \
       else if (prev_had_patch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP + 1) : "memory");         \
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP) : "memory");                                 \
-      unsigned long long keep_;                                                                      \
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0" \
-                   : "=&s"(keep_) : "v"(bar_addr), "v"(1u) : "memory");                              \
+      SP_SIGNAL(landed_addr, 0);                                                                     \
     }                                                                                                \
-    if constexpr (FIRST && (N) == BAR) {                                                             \
-      bar_target += 8u;                                                                              \
-      for (;;) {                                                                                     \
-        unsigned seen_;                                                                              \
-        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen_) : "v"(bar_addr) : "memory"); \
-        if ((int)(__builtin_amdgcn_readfirstlane(seen_) - bar_target) >= 0) break;                   \
-      }                                                                                              \
+    if constexpr (FIRST && (N) == ARR) SP_SIGNAL(read_addr, 1);    /* READ: lgkmcnt(0) first */         \
+    if constexpr ((FIRST ? 0 : NM) + (N) == RW - PEEK) read_seen = SP_PEEK(read_addr);               \
+    if constexpr (FIRST && (N) == NM - PEEK) landed_seen = SP_PEEK(landed_addr);                     \
+    if constexpr (!FIRST && NM + (N) == RW) {                                                        \
+      read_target += 8u;                                                                             \
+      SP_AWAIT(read_seen, read_addr, read_target);                                                   \
       /* the ticket taken at the tile's start is older than every transfer still in flight here */    \
       if (c == 1 && tid == 0) {                                                                      \
         int t_ = ticket;                                                                             \
@@ -351,9 +377,8 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
         asm volatile("ds_write_b32 %0, %1" ::"v"(slot_addr), "v"(grid + t_) : "memory");             \
       }                                                                                              \
     }                                                                                                \
-    /* transfers: piece k of the wave (weights first) at chunk slot BAR + 1 + k * PSTEP, spread over the rest of the \
-       chunk - the CU's one vector-memory pipe takes 16 cycles per piece */                          \
-    constexpr int g_ = (FIRST ? 0 : NM) + (N) - BAR - 1;                                             \
+    /* transfers: piece k of the wave (weights first) at chunk slot PS0 + k * PSTEP */                \
+    constexpr int g_ = (FIRST ? 0 : NM) + (N) - PS0;                                                 \
     if constexpr (g_ >= 0 && g_ % PSTEP == 0 && g_ / PSTEP < WP) SP_W_ISSUE(g_ / PSTEP);              \
     if constexpr (!HALO && g_ >= 0 && g_ % PSTEP == 0 && g_ / PSTEP >= WP && g_ / PSTEP < WP + AP) SP_A_ADDR(g_ / PSTEP - WP, a_off); \
     if constexpr (!HALO && g_ >= ASEP && (g_ - ASEP) % PSTEP == 0 && (g_ - ASEP) / PSTEP >= WP && (g_ - ASEP) / PSTEP < WP + AP) \
@@ -381,9 +406,9 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   static_assert(NPH == 5, "SP_SLOT issues patch pieces 0..4");
 
   const unsigned slot_addr = smem_addr + (unsigned)SLOT;
-  const unsigned bar_addr = slot_addr + 4;     // arrivals of the split chunk barrier (monotonic)
-  unsigned bar_target = 0;
-  if (tid == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(bar_addr), "v"(0u) : "memory");
+  const unsigned read_addr = slot_addr + 4, landed_addr = slot_addr + 8;     // the two counters (monotonic)
+  unsigned read_target = 0, landed_target = 0, read_seen = 0, landed_seen = 0;
+  if (tid == 0) asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %2, %1" ::"v"(read_addr), "v"(0u), "v"(landed_addr) : "memory");
   // ---- prologue: chunks 0, 1 and 2 of the first tile (HALO: the patch of its first slice and three weight chunks)
   if constexpr (!HALO) SP_A_SETUP();
   SP_W_SETUP();
@@ -461,6 +486,8 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
           if (c == n_chunks - 1) SP_H_MASK(next_tile);
         }
       }
+      landed_target += 8u;
+      SP_AWAIT(landed_seen, landed_addr, landed_target);     // every wave's pieces of the next chunk are in LDS
       SP_READ_X(0, rd_a);
       SP_STEP(1, 0, false)
       if constexpr (HALO) {
@@ -548,6 +575,9 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
 #undef SP_PIN
 #undef SP_MFMA
 #undef SP_SLOT
+#undef SP_SIGNAL
+#undef SP_AWAIT
+#undef SP_PEEK
 #undef SP_SLOTS4
 #undef SP_STEP
 }

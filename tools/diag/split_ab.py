@@ -25,8 +25,9 @@ VARIANTS = {
               ("#define SP_H_ISSUE(Q, SLICE) dma_piece(", "#define SP_H_ISSUE(Q, SLICE) if (p.k_pad < 0) dma_piece("),
               ("    dma_piece(w_words, smem_addr + W_BASE + fw_stage", "    if (p.k_pad < 0) dma_piece(w_words, smem_addr + W_BASE + fw_stage")],
     # no chunk synchronisation (racy: timing only)
-    "nosync": [("      asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_mov_b64 %0, exec", "      if (p.k_pad < 0) asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_mov_b64 %0, exec"),
-               ("      for (;;) {                                                                                     \\", "      for (; p.k_pad < 0;) {                                                                         \\")],
+    "nosync": [("    asm volatile(\"s_mov_b64 %0, exec\\n\\ts_mov_b64 exec, 1\\n\\tds_add_u32 %1, %2", "    if (p.k_pad < 0) asm volatile(\"s_mov_b64 %0, exec\\n\\ts_mov_b64 exec, 1\\n\\tds_add_u32 %1, %2"),
+               ("  if ((int)(__builtin_amdgcn_readfirstlane(PEEKED) - (TARGET)) < 0) {", "  if (p.k_pad < 0) {"),
+               ("#define SP_PEEK(ADDR) (*reinterpret_cast<volatile lds_u32*>(ADDR))", "#define SP_PEEK(ADDR) 0u")],
     # no counted vmcnt wait at the arrival (racy: timing only)
     "nowait": [("      if (skip_waits > 0) --skip_waits;  ", "      if (p.k_pad >= 0) {} else if (skip_waits > 0) --skip_waits;  ")],
 }
