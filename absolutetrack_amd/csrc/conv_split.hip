@@ -449,6 +449,24 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   SP_CONV(0, 0) SP_CONV(0, 1) SP_CONV(0, 2) SP_CONV(0, 3)
   if constexpr (UNITS > 4) { SP_CONV(0, 4) SP_CONV(0, 5) SP_CONV(0, 6) SP_CONV(0, 7) }
 
+  // The residual of a tile: requested in front of the stores (see the epilogue); with 32-row waves (half the accumulators)
+  // there are registers to request it a whole chunk ahead, under the tile's last MFMAs.
+  constexpr bool EARLY_RES = MI * NI <= 2;
+  u32x4 rr[MI][NI][4];
+#define SP_RES_REQUEST()                                                                             \
+  {                                                                                                  \
+    const int tm_ = tile / tiles_n, tn_ = tile - tm_ * tiles_n;                                      \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                 \
+      const int m = tm_ * BM + wm * (MI * 32) + i * 32 + fr;                                         \
+      const bool m_ok = m < M;                                                                       \
+      _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                 \
+        _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4) {                                           \
+          const int n = tn_ * BN + wn * (NI * 32) + j * 32 + 8 * g4 + 4 * fh;                        \
+          const unsigned off = (m_ok && n < p.cout_store) ? (unsigned)(m * p.cout_store + n) * 4u : OOB; \
+          rr[i][j][g4] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0);                   \
+        }                                                                                            \
+    }                                                                                                \
+  }
   int tile = slot;
   for (;;) {
     const int ticket = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, q_rsrc, q_off, 0, 0);
@@ -473,6 +491,9 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
         SP_W_SETUP();
       }
       if constexpr (!HALO) SP_A_TAP();
+      if constexpr (EARLY_RES) {
+        if (c == n_chunks - 1) SP_RES_REQUEST();
+      }
       // first k-step: set 0; its slot 0 reads the second k-step of the same chunk into set 1
       SP_READ_X(1, rd_a);
       SP_STEP(0, 1, true)
@@ -510,26 +531,13 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
     {
       const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
       const float floor_v = p.relu ? 0.f : -__builtin_huge_valf();
-      u32x4 rr[MI][NI][4];
       float4 bb[NI][4];
 #pragma unroll
       for (int j = 0; j < NI; ++j)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4)
           bb[j][g4] = *reinterpret_cast<const float4*>(p.bias + tn * BN + wn * (NI * 32) + j * 32 + 8 * g4 + 4 * fh);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int m = tm * BM + wm * (MI * 32) + i * 32 + fr;
-        const bool m_ok = m < M;
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const int n = tn * BN + wn * (NI * 32) + j * 32 + 8 * g4 + 4 * fh;
-            const unsigned off = (m_ok && n < p.cout_store) ? (unsigned)(m * p.cout_store + n) * 4u : OOB;
-            rr[i][j][g4] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0);
-          }
-      }
+      if constexpr (!EARLY_RES) SP_RES_REQUEST();
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int m = tm * BM + wm * (MI * 32) + i * 32 + fr;
@@ -575,6 +583,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
 #undef SP_PIN
 #undef SP_MFMA
 #undef SP_SLOT
+#undef SP_RES_REQUEST
 #undef SP_SIGNAL
 #undef SP_AWAIT
 #undef SP_PEEK
