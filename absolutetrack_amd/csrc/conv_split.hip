@@ -21,11 +21,13 @@
 // conflict-free ds_read_b128 per (32 rows, 16 k, plane) - and they take the same 4 bytes per value as fp32.
 //
 // One workgroup of 8 waves per CU computes 256 x BN output tiles, K in chunks of 32 (two MFMA k-steps).  Operands go
-// global -> LDS by LDS-DMA into rings of 3 stages (pixels: im2col gather, XOR-swizzled 128-byte rows as in
-// conv_igemm.hip).  One synchronisation per chunk, in two halves through an LDS counter: a wave ARRIVES once its
-// reads of the chunk are done and its pieces of the next chunk have landed (a counted vmcnt that leaves the youngest
-// pixel pieces in flight), and only WAITS for the other waves in front of its first transfer into the freed buffers.
-// The transfers of a chunk are spread over its MFMA slots (the CU's vector-memory pipe takes 16 cycles per 1-KB piece).
+// global -> LDS by LDS-DMA.  Weights: a ring of three 1-chunk stages.  Pixels: either the im2col gather of conv_igemm.hip
+// into a ring of three stages (XOR-swizzled 128-byte rows), or - HALO, the stride-1 convolutions - the tile's input rows
+// of a 32-channel slice brought in once per slice (two buffers) and read by the nine taps at shifted rows.
+// One synchronisation per chunk through two LDS counters, each signalled long before it is awaited and looked at a few
+// MFMA slots before its use: LANDED (my pieces of the next chunk are in LDS: a counted vmcnt that leaves the youngest
+// batch in flight) before the reads of the next chunk, READ (my fragment reads of this chunk are done) before the
+// transfers into the buffers the chunk frees.  The transfers are spread over the chunk's second k-step.
 // Persistent grid with the same tile queue as conv_igemm.hip; the fetch side runs across tile boundaries.
 // Epilogue: scale + bias + residual + ReLU + 16-byte NHWC stores (the accumulator layout of the 32x32 MFMAs is the same
 // as in conv_igemm.hip: a lane owns one pixel, register quads are 4 consecutive channels).
@@ -49,11 +51,6 @@ constexpr unsigned OOB = 0xFFFFFF00u;
 
 // LDS-DMA piece (see conv_igemm.hip::dma16): per-lane byte offset + wave-uniform byte offset
 __device__ __forceinline__ void dma_piece(u32x4 rsrc, unsigned lds_addr, unsigned voffset, unsigned soffset) {
-#ifdef SP_M0_NORESTORE
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
-               :: "v"(voffset), "s"(lds_addr), "s"(rsrc), "s"(soffset) : "memory");
-  return;
-#endif
   unsigned keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
