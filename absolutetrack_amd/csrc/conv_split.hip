@@ -177,7 +177,6 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   unsigned h_off[NPH];          // per-lane byte offset of this wave's pieces of the fetch tile's patch (slice 0)
   unsigned h_buf = 0;           // byte offset of the patch buffer being filled
   int c_tap = 0, c_slice = 0;   // tap and slice of the chunk being computed
-  unsigned c_buf = 0;           // ... and its patch buffer
   int r_tap = 0;                // tap of the chunk the fragment reads are at (one k-step ahead of the MFMAs)
   unsigned r_buf = 0;
   unsigned rmask[MI];           // 9 validity bits (tap order) of the lane's pixel in fragment i of the tile being read
