@@ -119,11 +119,12 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   //           awaited before the first read of the next chunk (start of the second k-step).
   //   READ    signalled at slot ARR: my fragment reads of THIS chunk are done;
   //           awaited at chunk slot RW, in front of my first transfer into the buffers this chunk frees.
-  constexpr int ARR = RD0 + NWF + (NM >= 12 ? 4 : 0);   // well behind the chunk's last fragment read (its lgkmcnt(0) should not stall)
+  constexpr int ARR = RD0 + NWF + (NM >= 12 ? 2 : 0);   // behind the chunk's last fragment read and in front of the first look at a
+                                                         // counter: its lgkmcnt(0) then waits for fragment reads issued slots ago only
   constexpr int RW = NM + (NM >= 12 ? 1 : 0);            // chunk slot (second k-step) of the READ wait
   constexpr int PS0 = RW + 1;                            // chunk slot of the wave's first transfer
   constexpr int PEEK = NM >= 12 ? 3 : 2;                 // slots between the look at a counter and its use
-  static_assert(RW - PEEK >= ARR && NM - PEEK > 0, "the counters are looked at after the wave's own signal");
+  static_assert(RW - PEEK >= ARR && NM - PEEK >= ARR, "the counters are looked at after the wave's READ signal");
   constexpr int NPC = HALO ? WP + 1 : WP + AP;           // transfers of a wave per chunk
   constexpr int PSTEP = (2 * NM - PS0) / NPC;            // slots between two transfers of a wave
   constexpr int ASEP = PSTEP >= 2 ? 1 : 0;               // a pixel piece's offset arithmetic one slot ahead of its transfer
@@ -194,6 +195,30 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
     }                                                                                                \
   }
 #define SP_H_ISSUE(Q, SLICE) dma_piece(a_words, smem_addr + h_buf + (unsigned)((wave + 8 * (Q)) * 1024), h_off[Q], (unsigned)(SLICE) * 128u)
+  // The patch in buffer BUF, landed as fp32 rows (16-byte group g of a row at position g ^ swizzle), is split IN PLACE, once:
+  // a value's two fp16 pieces take its 4 bytes.  Lane l < 40 of every wave owns row 40 * wave + l: 8 reads, 16 pair
+  // conversions, 8 writes - group q = 4 * piece + k / 8 at position q ^ swizzle.  Every tap (and both waves that share the
+  // rows) then reads ready pieces: the split costs 1/18 of what it costs behind every fragment read.
+#define SP_H_CONVERT(BUF)                                                                            \
+  if (lane < HROWS / 8) {                                                                            \
+    const int row_ = (HROWS / 8) * wave + lane;                                                      \
+    const int sw_ = (row_ >> 1) & 7;                                                                 \
+    char* rp_ = smem + (BUF) + row_ * 128;                                                           \
+    float4 f_[8];                                                                                    \
+    _Pragma("unroll") for (int g4 = 0; g4 < 8; ++g4) f_[g4] = *reinterpret_cast<const float4*>(rp_ + ((g4 ^ sw_) << 4)); \
+    _Pragma("unroll") for (int kg = 0; kg < 4; ++kg) {                                               \
+      unsigned a0_, a1_, a2_, a3_, b0_, b1_, b2_, b3_;                                               \
+      split_pair(f_[2 * kg].x, f_[2 * kg].y, a0_, b0_);                                              \
+      split_pair(f_[2 * kg].z, f_[2 * kg].w, a1_, b1_);                                              \
+      split_pair(f_[2 * kg + 1].x, f_[2 * kg + 1].y, a2_, b2_);                                      \
+      split_pair(f_[2 * kg + 1].z, f_[2 * kg + 1].w, a3_, b3_);                                      \
+      u32x4 a_, b_;                                                                                  \
+      a_.x = a0_; a_.y = a1_; a_.z = a2_; a_.w = a3_;                                                \
+      b_.x = b0_; b_.y = b1_; b_.z = b2_; b_.w = b3_;                                                \
+      *reinterpret_cast<u32x4*>(rp_ + ((kg ^ sw_) << 4)) = a_;                                       \
+      *reinterpret_cast<u32x4*>(rp_ + (((4 + kg) ^ sw_) << 4)) = b_;                                 \
+    }                                                                                                \
+  }
 #define SP_H_MASK(TILE)                                                                              \
   {                                                                                                  \
     _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                 \
@@ -292,10 +317,13 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
       const int sh_ = (dy_ - 1) * wimg + dx_ - 1;                                                    \
       _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                               \
         const int row_ = lrow[i] + sh_;                                                              \
-        const unsigned a_ = r_buf + (unsigned)(row_ * 128) + (unsigned)((((4 * (S) + 2 * fh) ^ ((row_ >> 1) & 7))) << 4); \
+        /* the patch is already split (SP_H_CONVERT): 16-byte group 2S + fh of the first pieces, +4 for the remainders */ \
+        const unsigned a_ = r_buf + (unsigned)(row_ * 128) + (unsigned)((((2 * (S) + fh) ^ ((row_ >> 1) & 7))) << 4); \
         const unsigned a0_ = ((rmask[i] >> r_tap) & 1u) ? a_ : (unsigned)ZROW;                       \
-        xr[i][0] = *reinterpret_cast<const float4*>(smem + a0_);                                     \
-        xr[i][1] = *reinterpret_cast<const float4*>(smem + (a0_ ^ 16u));                             \
+        const u32x4 p0_ = *reinterpret_cast<const u32x4*>(smem + a0_);                               \
+        const u32x4 p1_ = *reinterpret_cast<const u32x4*>(smem + (a0_ ^ 64u));                       \
+        xp[S][i][0][0] = p0_.x; xp[S][i][0][1] = p0_.y; xp[S][i][0][2] = p0_.z; xp[S][i][0][3] = p0_.w; \
+        xp[S][i][1][0] = p1_.x; xp[S][i][1][1] = p1_.y; xp[S][i][1][2] = p1_.z; xp[S][i][1][3] = p1_.w; \
       }                                                                                              \
     } else {                                                                                         \
       _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
@@ -358,7 +386,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
       else if constexpr (!HALO) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP + AP) : "memory");       \
       else if (prev_had_patch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP + 1) : "memory");         \
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP) : "memory");                                 \
-      SP_SIGNAL(landed_addr, 0);                                                                     \
+      SP_SIGNAL(landed_addr, 0);                                                                              \
     }                                                                                                \
     if constexpr (FIRST && (N) == ARR) SP_SIGNAL(read_addr, 1);    /* READ: lgkmcnt(0) first */         \
     if constexpr ((FIRST ? 0 : NM) + (N) == RW - PEEK) read_seen = SP_PEEK(read_addr);               \
@@ -386,7 +414,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
       else if (c_tap == 3) SP_H_ISSUE(3, f_slice);                                                   \
       else if (c_tap == 4) SP_H_ISSUE(4, f_slice);                                                   \
     }                                                                                                \
-    if constexpr ((N) >= CV0 && (N) - CV0 < UNITS) SP_CONV(NXT, (N) - CV0);                          \
+    if constexpr (!HALO && (N) >= CV0 && (N) - CV0 < UNITS) SP_CONV(NXT, (N) - CV0);                 \
     if constexpr ((N) >= RD0 && (N) - RD0 < NWF) SP_READ_W1(NXT, FIRST ? 1 : 0, (N) - RD0);          \
     SP_PIN();                                                                                        \
     SP_MFMA(CUR, N);                                                                                 \
@@ -440,10 +468,17 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
     for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  if constexpr (HALO) {
+    SP_H_CONVERT(0u);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   SP_READ_X(0, 0u);
   SP_READ_WALL(0, 0);
-  SP_CONV(0, 0) SP_CONV(0, 1) SP_CONV(0, 2) SP_CONV(0, 3)
-  if constexpr (UNITS > 4) { SP_CONV(0, 4) SP_CONV(0, 5) SP_CONV(0, 6) SP_CONV(0, 7) }
+  if constexpr (!HALO) {
+    SP_CONV(0, 0) SP_CONV(0, 1) SP_CONV(0, 2) SP_CONV(0, 3)
+    if constexpr (UNITS > 4) { SP_CONV(0, 4) SP_CONV(0, 5) SP_CONV(0, 6) SP_CONV(0, 7) }
+  }
 
   // The residual of a tile: requested in front of the stores (see the epilogue); with 32-row waves (half the accumulators)
   // there are registers to request it a whole chunk ahead, under the tile's last MFMAs.
@@ -505,6 +540,14 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
       }
       landed_target += 8u;
       SP_AWAIT(landed_seen, landed_addr, landed_target);     // every wave's pieces of the next chunk are in LDS
+      if constexpr (HALO) {
+        // every piece of the patch being fetched (issued with taps 0..4) has landed for every wave two chunks ago: split it;
+        // the LANDED signal of the next chunk publishes the pieces (written by now) before the slice's first read
+        if (c_tap == 7) {
+          SP_H_CONVERT(h_buf);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      }
       SP_READ_X(0, rd_a);
       SP_STEP(1, 0, false)
       if constexpr (HALO) {
@@ -564,6 +607,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
 #undef SP_H_SETUP
 #undef SP_H_ISSUE
 #undef SP_H_MASK
+#undef SP_H_CONVERT
 #undef SP_A_SETUP
 #undef SP_W_SETUP
 #undef SP_A_TAP
