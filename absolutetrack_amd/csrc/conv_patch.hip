@@ -101,6 +101,32 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
   const int M = p.n_img * H * W;
   const unsigned smem_addr = (unsigned)(unsigned long)(lds_f32p*)smem;
 
+  // SPLIT: a landed patch (fp32 rows, 16-byte group g at position g ^ swizzle) is split IN PLACE, once per tile - a value's
+  // two fp16 pieces take its 4 bytes; group q = 4 * piece + k / 8 at position q ^ swizzle.  Thread t < PROWS owns row t.
+  // The nine taps then read ready pieces instead of splitting the same values nine times.
+  auto convert_patch = [&](int buf) {
+    if (tid < PROWS) {
+      const int sw = (tid >> 1) & 7;
+      char* rp = reinterpret_cast<char*>(smem) + (size_t)(W_FLOATS + buf * P_FLOATS) * 4 + tid * 128;
+      float4 f[8];
+#pragma unroll
+      for (int g4 = 0; g4 < 8; ++g4) f[g4] = *reinterpret_cast<const float4*>(rp + ((g4 ^ sw) << 4));
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) {
+        unsigned a0, a1, a2, a3, b0, b1, b2, b3;
+        split_pair_p(f[2 * kg].x, f[2 * kg].y, a0, b0);
+        split_pair_p(f[2 * kg].z, f[2 * kg].w, a1, b1);
+        split_pair_p(f[2 * kg + 1].x, f[2 * kg + 1].y, a2, b2);
+        split_pair_p(f[2 * kg + 1].z, f[2 * kg + 1].w, a3, b3);
+        u32x4 a, b;
+        a.x = a0; a.y = a1; a.z = a2; a.w = a3;
+        b.x = b0; b.y = b1; b.z = b2; b.w = b3;
+        *reinterpret_cast<u32x4*>(rp + ((kg ^ sw) << 4)) = a;
+        *reinterpret_cast<u32x4*>(rp + (((4 + kg) ^ sw) << 4)) = b;
+      }
+    }
+  };
+
   const u32x4 in_words = rsrc_words(p.in, (unsigned)((size_t)M * C * sizeof(float)));
   const u32x4 w_words = SPLIT ? rsrc_words(p.w_split, (unsigned)(W_FLOATS * 4))
                               : rsrc_words(p.w, (unsigned)((size_t)p.cout_pad * p.k_pad * sizeof(float)));
@@ -220,6 +246,11 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
+  if constexpr (SPLIT) {
+    convert_patch(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   int next = slot_read(2);
   int cur = 0;
 
@@ -299,33 +330,26 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
 #undef UTP_MFMA
 #undef UTP_PIN
     } else {
-      // 9 taps x 2 k-steps of 16: per step two b128 reads of the lane's 8 patch values, the split, the two weight
-      // planes (one conflict-free b128 each) and three MFMAs; the next step's reads are issued ahead of the MFMAs
-      float4 prX[2], prY[2];
+      // 9 taps x 2 k-steps of 16: per step two b128 reads of the lane's 8 patch values (already split: convert_patch), the
+      // two weight planes (one conflict-free b128 each) and three MFMAs; the next step's reads are issued ahead of the MFMAs
+      u32x4 prX[2], prY[2];      // the lane's 8 values of the step: first pieces, remainders
       u32x4 wqX[2], wqY[2];
       const char* w_bytes = reinterpret_cast<const char*>(smem) + lane * 16;
+      const char* p_bytes = reinterpret_cast<const char*>(patch);
 #define UTS_READ(SET, TAP, S)                                                                        \
   {                                                                                                  \
     const int pidx_ = pbase + ((TAP) / 3) * PW + ((TAP) % 3);                                        \
-    const int sw_ = (pidx_ >> 1) & 7;                                                                \
-    pr##SET[0] = *reinterpret_cast<const float4*>(patch + pidx_ * C + 4 * ((4 * (S) + 2 * fh) ^ sw_));     \
-    pr##SET[1] = *reinterpret_cast<const float4*>(patch + pidx_ * C + 4 * ((4 * (S) + 2 * fh + 1) ^ sw_)); \
+    const int off_ = pidx_ * 128 + (((2 * (S) + fh) ^ ((pidx_ >> 1) & 7)) << 4);                     \
+    pr##SET[0] = *reinterpret_cast<const u32x4*>(p_bytes + off_);                                    \
+    pr##SET[1] = *reinterpret_cast<const u32x4*>(p_bytes + (off_ ^ 64));                             \
     wq##SET[0] = *reinterpret_cast<const u32x4*>(w_bytes + (((TAP) * 2 + (S)) * 2 + 0) * 1024);      \
     wq##SET[1] = *reinterpret_cast<const u32x4*>(w_bytes + (((TAP) * 2 + (S)) * 2 + 1) * 1024);      \
   }
 #define UTS_MFMA(SET)                                                                                \
   {                                                                                                  \
-    unsigned a0_, a1_, b0_, b1_, c0_, c1_, d0_, d1_;                                                 \
-    split_pair_p(pr##SET[0].x, pr##SET[0].y, a0_, a1_);                                              \
-    split_pair_p(pr##SET[0].z, pr##SET[0].w, b0_, b1_);                                              \
-    split_pair_p(pr##SET[1].x, pr##SET[1].y, c0_, c1_);                                              \
-    split_pair_p(pr##SET[1].z, pr##SET[1].w, d0_, d1_);                                              \
-    u32x4 p0_, p1_;                                                                                  \
-    p0_.x = a0_; p0_.y = b0_; p0_.z = c0_; p0_.w = d0_;                                              \
-    p1_.x = a1_; p1_.y = b1_; p1_.z = c1_; p1_.w = d1_;                                              \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8p, wq##SET[0]), __builtin_bit_cast(f16x8p, p1_), acc, 0, 0, 0); \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8p, wq##SET[1]), __builtin_bit_cast(f16x8p, p0_), acc, 0, 0, 0); \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8p, wq##SET[0]), __builtin_bit_cast(f16x8p, p0_), acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8p, wq##SET[0]), __builtin_bit_cast(f16x8p, pr##SET[1]), acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8p, wq##SET[1]), __builtin_bit_cast(f16x8p, pr##SET[0]), acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8p, wq##SET[0]), __builtin_bit_cast(f16x8p, pr##SET[0]), acc, 0, 0, 0); \
   }
 #define UTS_PIN() __builtin_amdgcn_sched_barrier(0)
       UTS_READ(X, 0, 0);
@@ -358,6 +382,11 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
     // every wave's pieces of the next patch have landed and everyone is done reading the current one
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
     __builtin_amdgcn_s_barrier();
+    if constexpr (SPLIT) {                // the next tile's patch is complete: split it in place, once
+      convert_patch(cur ^ 1);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
+    }
     const int next2 = slot_read(cur);
     tile = next;
     next = next2;

@@ -25,5 +25,7 @@ extern "C" int conv_diag2(const float* in, const float* w, const void* w_split, 
   if (!cnt) (void)hipMalloc((void**)&cnt, 4);
   (void)hipMemsetAsync(cnt, 0, 4, 0);
   c.tile_counter = cnt;
-  return (int)(mode ? ut::launch_conv_split(c, 0) : ut::launch_conv_igemm(c, 0));
+  if (!mode) c.w_split = nullptr;
+  // mode 1: the split-fp16 kernel for the shape (conv_split.hip, or the split instantiation of the layer1 patch kernel)
+  return (int)(mode && ut::conv_split_applicable(c) ? ut::launch_conv_split(c, 0) : ut::launch_conv_igemm(c, 0));
 }
