@@ -354,6 +354,8 @@ class HipEngine:
                 raise AssertionError(msg)      # the reference asserts here (umetrack_model.py:224-229)
             if rc == -1 and "index check:" in msg:
                 raise IndexError(msg)          # the reference's tensor indexing raises IndexError on these
+            if rc == -1 and "range check:" in msg:
+                raise FloatingPointError(msg)  # split-fp16 backbone: an activation left the range two fp16 pieces hold
             raise RuntimeError(f"{what} failed ({rc}): {msg}")
         return rc
 

@@ -261,7 +261,10 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
       const int n = 8 * g4 + 4 * fh;                                                                 \
       u32x4 pk;                                                                                      \
       float v0 = acc[4 * g4], v1 = acc[4 * g4 + 1], v2 = acc[4 * g4 + 2], v3 = acc[4 * g4 + 3];      \
-      if constexpr (SPLIT) { v0 *= p.split_unscale; v1 *= p.split_unscale; v2 *= p.split_unscale; v3 *= p.split_unscale; } \
+      if constexpr (SPLIT) {                                                                         \
+        v0 *= p.split_unscale; v1 *= p.split_unscale; v2 *= p.split_unscale; v3 *= p.split_unscale;  \
+        out_max = fmaxf(fmaxf(out_max, fmaxf(fabsf(v0), fabsf(v1))), fmaxf(fabsf(v2), fabsf(v3)));    \
+      }                                                                                              \
       if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); } \
       pk.x = __float_as_uint(v0); pk.y = __float_as_uint(v1); pk.z = __float_as_uint(v2); pk.w = __float_as_uint(v3); \
       __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, (unsigned)(m_ * C + n) * 4u, 0, 0);         \
@@ -274,6 +277,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
 #endif
   bool have_prev = false;
   int prev_m = 0;
+  float out_max = 0.f;      // SPLIT: largest output magnitude of this lane (range guard: the next layer splits it into fp16 pieces)
   f32x16 ready = init_combine();      // bias + residual of the tile about to be computed
   f32x16 acc;
   for (;;) {
@@ -394,6 +398,9 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
     cur ^= 1;
   }
   if (late && have_prev) { UTP_EPILOGUE(prev_m); }
+  if constexpr (SPLIT) {
+    if (!(out_max < 65504.f) && p.status) atomicOr(p.status, UT_SPLIT_RANGE);
+  }
 #undef UTP_EPILOGUE
 }
 

@@ -498,6 +498,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
         }                                                                                            \
     }                                                                                                \
   }
+  float out_max = 0.f;          // largest output magnitude of this lane so far (range guard of the split arithmetic)
   int tile = slot;
   for (;;) {
     const int ticket = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, q_rsrc, q_off, 0, 0);
@@ -592,6 +593,8 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
             pk.y = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 1], p.split_unscale, bb[j][g4].y + __uint_as_float(rr[i][j][g4].y)), floor_v));
             pk.z = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 2], p.split_unscale, bb[j][g4].z + __uint_as_float(rr[i][j][g4].z)), floor_v));
             pk.w = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 3], p.split_unscale, bb[j][g4].w + __uint_as_float(rr[i][j][g4].w)), floor_v));
+            out_max = fmaxf(fmaxf(out_max, fmaxf(fabsf(__uint_as_float(pk.x)), fabsf(__uint_as_float(pk.y)))),
+                            fmaxf(fabsf(__uint_as_float(pk.z)), fabsf(__uint_as_float(pk.w))));
             __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, off, 0, 0);
           }
 #pragma unroll
@@ -600,6 +603,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
       }
       skip_waits = 2;
     }
+    if (!(out_max < 65504.f) && p.status) atomicOr(p.status, UT_SPLIT_RANGE);   // (also a NaN): the next layer could not split it
     if (next_tile >= n_tiles) break;
     tile = next_tile;
   }

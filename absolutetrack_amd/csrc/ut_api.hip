@@ -177,6 +177,8 @@ int stateless_status(int* device_out, DevStatus* out) {
 }
 
 const char* status_message(int bits) {
+  if (bits & ut::UT_SPLIT_RANGE)
+    return "range check: an activation of the split-fp16 backbone reached |x| >= 65504, beyond what two fp16 pieces hold: use UT_CONV_FP32";
   if (bits & ut::UT_BAD_SRC_INDEX) return "index check: src_index outside [0, n_src_images)";
   if (bits & ut::UT_BAD_SAMPLE_RANGE) return "index check: sample_range rows must select 1 or 2 crops inside [0, n_crops]";
   if (bits & ut::UT_BAD_MEMORY_IDX) return "index check: memory_idx outside [0, n_slots)";
@@ -455,6 +457,7 @@ int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, fl
   const bool split = h->conv_arith == UT_CONV_SPLIT_F16_ALWAYS || (h->conv_arith == UT_CONV_SPLIT_F16 && tiles256 >= 2l * h->num_cu);
   c.w_split = split && !h->latency_mode ? cw.w_split : nullptr;
   c.split_unscale = cw.split_unscale;
+  c.status = h->status;
   pe.kind = c.w_split && (ut::conv_split_applicable(c) || ut::conv_patch_applicable(c)) ? 1 : 0;
   if (c.w_split && ut::conv_split_applicable(c)) HIPCHK(h, ut::launch_conv_split(c, s));
   else HIPCHK(h, ut::launch_conv_igemm(c, s));
@@ -640,7 +643,7 @@ int ut_warp_crops(ut_handle h, const uint8_t* src, int n_src_images, int src_h, 
     int sticky = 0, call = 0, rc = read_status(h, st_dev, st_host, s, &sticky, &call);
     if (rc) return rc;
     if (sticky & ut::UT_STATUS_ERRORS) {
-      char buf[160];
+      char buf[256];
       snprintf(buf, sizeof buf, "ut_warp_crops: %s", status_message(sticky));
       return fail(h, UT_E_INVALID, buf);
     }
@@ -782,7 +785,7 @@ int ut_warp_backbone(ut_handle h, const uint8_t* src, int n_src_images, int src_
     int sticky = 0, call = 0, rc = read_status(h, h->status, h->status_host, s, &sticky, &call);
     if (rc) return rc;
     if (sticky & ut::UT_STATUS_ERRORS) {
-      char buf[160];
+      char buf[256];
       snprintf(buf, sizeof buf, "ut_warp_backbone: %s", status_message(sticky));
       return fail(h, UT_E_INVALID, buf);
     }
@@ -832,7 +835,7 @@ int ut_fuse_temporal_regress(ut_handle h, const float* feat, const float* intrin
     int sticky = 0, call = 0;
     if ((rc = read_status(h, h->status, h->status_host, s, &sticky, &call))) return rc;
     if (sticky & ut::UT_STATUS_ERRORS) {
-      char buf[160];
+      char buf[256];
       snprintf(buf, sizeof buf, "ut_fuse_temporal_regress: %s", status_message(sticky));
       return fail(h, UT_E_INVALID, buf);
     }
@@ -1001,7 +1004,7 @@ int ut_poll_status(ut_handle h, void* stream) {
   int sticky = 0, call = 0, rc = read_status(h, h->status, h->status_host, (hipStream_t)stream, &sticky, &call);
   if (rc) return rc;
   if (sticky & ut::UT_STATUS_ERRORS) {
-    char buf[160];
+    char buf[256];
     snprintf(buf, sizeof buf, "reported late (deferred checks): %s", status_message(sticky));
     return fail(h, UT_E_INVALID, buf);
   }

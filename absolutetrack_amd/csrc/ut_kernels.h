@@ -17,6 +17,7 @@ struct ConvLaunch {
   const float* w;      // [cout_pad][k_pad]
   const void* w_split; // optional: the two fp16 planes of (w * scale) in fragment order (conv_split.hip), or null
   float split_unscale; // 1 / scale of w_split
+  int* status;         // split kernels: sticky status word, UT_SPLIT_RANGE is set when an output leaves the fp16-split range
   const float* bias;   // [cout_pad]
   const float* res;    // optional residual, same layout as out
   float* out;          // NHWC [n_img, Ho, Wo, cout_store] or NCHW [n_img, cout_store, Ho*Wo]
@@ -79,8 +80,9 @@ enum : int {
   UT_BAD_HAND_IDX = 8,       // hand_idx not 0 / 1
   UT_SINGLE_VIEW = 16,       // informational: at least one one-view sample (an error only in unknown-skeleton mode)
   UT_BAD_SRC_INDEX = 32,     // ut_warp_crops: src_index outside [0, n_src_images)
+  UT_SPLIT_RANGE = 64,       // split-fp16 convolutions: an activation of magnitude >= 65504 (the next layer could not split it)
 };
-constexpr int UT_STATUS_ERRORS = UT_BAD_SAMPLE_RANGE | UT_BAD_MEMORY_IDX | UT_DUP_MEMORY_IDX | UT_BAD_HAND_IDX | UT_BAD_SRC_INDEX;
+constexpr int UT_STATUS_ERRORS = UT_BAD_SAMPLE_RANGE | UT_BAD_MEMORY_IDX | UT_DUP_MEMORY_IDX | UT_BAD_HAND_IDX | UT_BAD_SRC_INDEX | UT_SPLIT_RANGE;
 
 struct HeadArgs {
   const float* feat;        // [N,72,36] NCHW

@@ -87,7 +87,10 @@ int ut_set_backbone_lanes(ut_handle h, int lanes);
  *                      piece products per k on v_mfma_f32_32x32x16_f16, fp32 accumulation: the terms dropped are ~2^-22
  *                      of a product, so the result carries fp32-level rounding error (not the fp32 chain's bits: outputs
  *                      agree with UT_CONV_FP32 to ~1e-6 relative) at up to 5.3x the matrix rate.  Precondition:
- *                      |activation| < 65504 (fp16's range; the network's post-BatchNorm activations are O(1..100)).
+ *                      |activation| < 65504 (fp16's range; the network's post-BatchNorm activations are O(1..100)),
+ *                      checked on the device: an output of a split convolution beyond it sets a sticky status bit
+ *                      that the next status read (ut_poll_status, or any call that reads the index checks in
+ *                      UT_CHECK_SYNC mode) returns as UT_E_INVALID "range check: ...".
  *  UT_CONV_SPLIT_F16_ALWAYS  the same kernel also for launches too small to fill the chip (slower there: for tests).
  * Every other launch (stem, layer1, 1x1 shortcuts, head, and all launches in latency mode) is unaffected. */
 enum { UT_CONV_FP32 = 0, UT_CONV_SPLIT_F16 = 1, UT_CONV_SPLIT_F16_ALWAYS = 2 };

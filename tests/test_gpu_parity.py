@@ -105,6 +105,27 @@ def test_split_f16_backbone_matches_oracle(engine, split_engine):
     assert torch.equal(split_engine.backbone(_dev(crops)).cpu(), got)       # deterministic
 
 
+def test_split_f16_range_guard():
+    """The split arithmetic holds an activation in two fp16 pieces, i.e. up to |x| < 65504: a network whose activations leave
+    that range (here: one convolution's weights scaled by 1e6) is reported - a sticky device-side flag, raised at the next
+    status read - instead of silently saturating; the exact-fp32 mode runs the same weights without complaint."""
+    sd = dict(synth.synthetic_state_dict(0))
+    k = "_feature_extractor._image_backbone.0._layers.2.0.conv2.weight"
+    sd[k] = sd[k] * np.float32(1e6)
+    crops = _dev(synth.synthetic_crops(6, seed=4))
+    eng = _native.HipEngine(sd, DEV)
+    try:
+        eng.backbone(crops)
+        eng.poll_status()                                   # fp32 mode: nothing to report
+        eng.set_conv_arithmetic("split_f16_always")
+        eng.backbone(crops)
+        with pytest.raises(FloatingPointError, match="65504"):
+            eng.poll_status()
+        eng.poll_status()                                   # the flag was cleared by the read that reported it
+    finally:
+        eng.close()
+
+
 def test_split_f16_large_batch(engine):
     """The default split mode engages on launches that fill the chip: 2048 + 37 crops (ragged last tiles at every
     resolution), against the fp32-MFMA mode on the same crops and the oracle on a few of them."""
