@@ -217,6 +217,22 @@ def main():
                 "launches_per_step": l0 // n_prof, "ms_per_step": round(ms0 / n_prof, 4),
                 "achieved": round(f0 / (ms0 * 1e-3) / 1e12, 3), "peak": PEAK_FP32_MFMA_TFLOPS}
 
+    # the same profiling pass with the exact-fp32 convolutions, for the fp32-MFMA roofline beside the split one
+    roofline_fp32 = None
+    if roofline is not None and args.conv != "fp32" and not args.no_fp32_mode:
+        eng.set_conv_arithmetic("fp32")
+        eng.profile_begin()
+        for _ in range(2):
+            hot.step(batch)
+        ms32, l32, f32_ = eng.profile_end_by_kind()[0]
+        eng.set_conv_arithmetic(args.conv)
+        hot.check()
+        a32 = f32_ / (ms32 * 1e-3) / 1e12 if ms32 > 0 else 0.0
+        roofline_fp32 = {"bound": "mfma", "kernel": "conv_igemm_kernel (all instantiations) + conv3x3_c32_patch_kernel (layer1)",
+                         "achieved": round(a32, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(a32 / PEAK_FP32_MFMA_TFLOPS, 4), "launches_per_step": l32 // 2,
+                         "avg_launch_ms": round(ms32 / max(l32, 1), 5)}
+
     cpu, batched = None, None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         from oracle import checks
@@ -257,7 +273,7 @@ def main():
                        "outputs_finite": finite},
             "conv_arithmetic": args.conv, "split_f16_check": split_check, "exact_fp32_mode": fp32_mode,
             "parity_batched_vs_oracle": batched,
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_exact_fp32_mode": roofline_fp32, "cpu_baseline": cpu,
             "mpjpe_delta_mm": None if parity is None else parity["mpjpe_delta_mm"], "parity_recording_00": parity,
         }
         print(json.dumps(line), flush=True)
