@@ -103,7 +103,8 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   constexpr int HROWS = 320;               // HALO: patch rows per slice (256 + 2 * (image width + 1) <= 320: width <= 31)
   constexpr int NPH = HROWS / 64;          // ... 1-KB pieces per wave
   constexpr int A_STAGE = HALO ? HROWS * 128 : BM * 128, W_STAGE = BN * 128;
-  constexpr int A_RING = HALO ? 2 : 3, W_RING = 3;
+  constexpr int A_RING = HALO ? 2 : 3, W_RING = HALO ? 4 : 3;   // stages; the weight stream runs 3 chunks ahead
+  constexpr int W_AHEAD = 3;
   constexpr int W_BASE = A_RING * A_STAGE;
   constexpr int ZROW = W_BASE + W_RING * W_STAGE;          // 128 bytes of zeros (HALO: the target of out-of-image taps)
   constexpr int SLOT = ZROW + 128;
@@ -388,12 +389,18 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP) : "memory");                                 \
       SP_SIGNAL(landed_addr, 0);                                                                              \
     }                                                                                                \
-    if constexpr (FIRST && (N) == ARR) SP_SIGNAL(read_addr, 1);    /* READ: lgkmcnt(0) first */         \
-    if constexpr ((FIRST ? 0 : NM) + (N) == RW - PEEK) read_seen = SP_PEEK(read_addr);               \
+    /* READ is needed only where a stage is refilled in the chunk that read it (rings of 3: the gather instantiation). \
+       With the HALO instantiation's weight ring of 4 the stage refilled in chunk g is that of chunk g - 1, and every   \
+       wave that has signalled LANDED in chunk g (awaited before the second k-step) has finished reading it; the same   \
+       holds for the patch buffer of the previous slice.  One synchronisation per chunk instead of two. */ \
+    if constexpr (!HALO && FIRST && (N) == ARR) SP_SIGNAL(read_addr, 1);    /* lgkmcnt(0) first */      \
+    if constexpr (!HALO && (FIRST ? 0 : NM) + (N) == RW - PEEK) read_seen = SP_PEEK(read_addr);       \
     if constexpr (FIRST && (N) == NM - PEEK) landed_seen = SP_PEEK(landed_addr);                     \
     if constexpr (!FIRST && NM + (N) == RW) {                                                        \
-      read_target += 8u;                                                                             \
-      SP_AWAIT(read_seen, read_addr, read_target);                                                   \
+      if constexpr (!HALO) {                                                                         \
+        read_target += 8u;                                                                           \
+        SP_AWAIT(read_seen, read_addr, read_target);                                                 \
+      }                                                                                              \
       /* the ticket taken at the tile's start is older than every transfer still in flight here */    \
       if (c == 1 && tid == 0) {                                                                      \
         int t_ = ticket;                                                                             \
@@ -449,7 +456,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
     f_slice = n_slices > 1 ? 1 : 0;
   }
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
+  for (int c = 0; c < W_AHEAD; ++c) {
     if constexpr (!HALO) {
       SP_A_TAP();
 #pragma unroll
@@ -518,7 +525,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
           SP_A_SETUP();
         }
       }
-      if (c == n_chunks - 3) {
+      if (c == n_chunks - W_AHEAD) {
         fw_tile = next_tile;
         SP_W_SETUP();
       }
@@ -641,7 +648,7 @@ hipError_t launch_split_cfg(const ConvLaunch& c, hipStream_t s) {
   const int tiles_m = (M + BM - 1) / BM;
   const int tiles_n = (c.cout_store + BN - 1) / BN;
   const int n_tiles = tiles_m * tiles_n;
-  const size_t lds = (HALO ? 2 * (size_t)320 * 128 : 3 * (size_t)BM * 128) + 3 * (size_t)BN * 128 + 128 + 16;
+  const size_t lds = (HALO ? 2 * (size_t)320 * 128 : 3 * (size_t)BM * 128) + (HALO ? 4 : 3) * (size_t)BN * 128 + 128 + 16;
   static std::atomic<unsigned long long> attr_set{0};
   const unsigned long long dev_bit = (c.device >= 0 && c.device < 64) ? 1ull << c.device : 0ull;
   if (!(attr_set.load(std::memory_order_relaxed) & dev_bit) || !dev_bit) {

@@ -28,6 +28,10 @@ VARIANTS = {
     "nosync": [("    asm volatile(\"s_mov_b64 %0, exec\\n\\ts_mov_b64 exec, 1\\n\\tds_add_u32 %1, %2", "    if (p.k_pad < 0) asm volatile(\"s_mov_b64 %0, exec\\n\\ts_mov_b64 exec, 1\\n\\tds_add_u32 %1, %2"),
                ("  if ((int)(__builtin_amdgcn_readfirstlane(PEEKED) - (TARGET)) < 0) {", "  if (p.k_pad < 0) {"),
                ("#define SP_PEEK(ADDR) (*reinterpret_cast<volatile lds_u32*>(ADDR))", "#define SP_PEEK(ADDR) 0u")],
+    # READ signal without its lgkmcnt(0) (racy: timing only)
+    "nolgkm": [("SP_SIGNAL(read_addr, 1);", "SP_SIGNAL(read_addr, 0);")],
+    # signals and looks, but no waiting on the counters (racy: timing only)
+    "noawait": [("  if ((int)(__builtin_amdgcn_readfirstlane(PEEKED) - (TARGET)) < 0) {", "  if (p.k_pad < 0 && (int)(__builtin_amdgcn_readfirstlane(PEEKED) - (TARGET)) < 0) {")],
     # no counted vmcnt wait at the arrival (racy: timing only)
     "nowait": [("      if (skip_waits > 0) --skip_waits;  ", "      if (p.k_pad >= 0) {} else if (skip_waits > 0) --skip_waits;  ")],
 }
