@@ -355,7 +355,7 @@ class HipEngine:
             if rc == -1 and "index check:" in msg:
                 raise IndexError(msg)          # the reference's tensor indexing raises IndexError on these
             if rc == -1 and "range check:" in msg:
-                raise FloatingPointError(msg)  # split-fp16 backbone: an activation left the range two fp16 pieces hold
+                raise FloatingPointError(msg)  # split-fp16 backbone: an infinity / a NaN among a layer's input activations
             raise RuntimeError(f"{what} failed ({rc}): {msg}")
         return rc
 
@@ -377,8 +377,8 @@ class HipEngine:
 
     def set_conv_arithmetic(self, mode: str):
         """"fp32": exact fp32 matrix instructions (default).  "split_f16": the batched backbone convolutions run on the fp16
-        matrix cores from two-piece splits of both operands (fp32-level error, not the fp32 chain's bits);
-        "split_f16_always": also the launches too small to fill the chip (tests)."""
+        matrix cores from two-piece splits of both operands (fp32-level error, not the fp32 chain's bits), for calls of
+        >= 2 x CUs crops (one arithmetic per call); "split_f16_always": calls of any size (tests)."""
         self._check(self.lib.ut_set_conv_arithmetic(self._h, {"fp32": 0, "split_f16": 1, "split_f16_always": 2}[mode]), "ut_set_conv_arithmetic")
 
     def poll_status(self):

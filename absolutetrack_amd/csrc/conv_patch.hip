@@ -25,12 +25,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) float lds_f32p;
 
 namespace {
-#ifdef UTP_NARROW                            /* diag: the earlier 16 x 16 tile, 8 waves = two per SIMD */
-constexpr int TY = 16, TX = 16, NW = 8;
-#else
 constexpr int TY = 16, TX = 24, NW = 12;    // output tile is TY x TX pixels, one 32-pixel block per wave: 12 waves,
                                             // three per SIMD (+3.7 % over two), 157.7 KB of the CU's 160 KB LDS
-#endif
 static_assert(TY * TX == 32 * NW, "one 32-pixel block per wave");
 constexpr int PW = TX + 2, PH = TY + 2;     // patch width / height
 constexpr int PPIX = PW * PH;               // 324 (468) patch pixels
@@ -67,6 +63,8 @@ __device__ __forceinline__ u32x4 rsrc_words(const void* base, unsigned bytes) {
 // ConvLaunch::w_split in fragment order (the same 36 KB), the patch stays fp32 in LDS and is split in registers, the
 // accumulators hold scale x (sum) and start at scale x (bias + residual).  Nine taps x 6 MFMAs of 32 cycles instead of
 // 9 x 16 of 64: the kernel is then bound by the tile's HBM traffic (patch in, residual in, tile out), not by the matrix pipe.
+// The activations are multiplied by a power of two taken from the producer's max word before they are split
+// (ut_kernels.h::split_act_scale), so the split has no precondition on their magnitude; the kernel leaves its own max word.
 typedef _Float16 f16x8p __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2p __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_pair_p(float a, float b, unsigned& p0, unsigned& p1) {
@@ -104,13 +102,24 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
   // SPLIT: a landed patch (fp32 rows, 16-byte group g at position g ^ swizzle) is split IN PLACE, once per tile - a value's
   // two fp16 pieces take its 4 bytes; group q = 4 * piece + k / 8 at position q ^ swizzle.  Thread t < PROWS owns row t.
   // The nine taps then read ready pieces instead of splitting the same values nine times.
+  float x_scale = 1.f, x_unscale = 1.f;      // SPLIT: power-of-two activation scale and its inverse
+  if constexpr (SPLIT) {
+    if (p.in_max) {
+      bool ok;
+      split_act_scale(p.in_max, x_scale, x_unscale, ok);
+      if (!ok && tid == 0 && blockIdx.x == 0 && p.status) atomicOr(p.status, UT_SPLIT_RANGE);
+    }
+  }
   auto convert_patch = [&](int buf) {
     if (tid < PROWS) {
       const int sw = (tid >> 1) & 7;
       char* rp = reinterpret_cast<char*>(smem) + (size_t)(W_FLOATS + buf * P_FLOATS) * 4 + tid * 128;
       float4 f[8];
 #pragma unroll
-      for (int g4 = 0; g4 < 8; ++g4) f[g4] = *reinterpret_cast<const float4*>(rp + ((g4 ^ sw) << 4));
+      for (int g4 = 0; g4 < 8; ++g4) {
+        f[g4] = *reinterpret_cast<const float4*>(rp + ((g4 ^ sw) << 4));
+        f[g4].x *= x_scale; f[g4].y *= x_scale; f[g4].z *= x_scale; f[g4].w *= x_scale;
+      }
 #pragma unroll
       for (int kg = 0; kg < 4; ++kg) {
         unsigned a0, a1, a2, a3, b0, b1, b2, b3;
@@ -212,7 +221,8 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
     for (int g4 = 0; g4 < 4; ++g4)
       res_raw[g4] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, (unsigned)(m * C + 8 * g4 + 4 * fh) * 4u, 0, 0);
   };
-  const float acc_scale = SPLIT ? 1.0f / p.split_unscale : 1.0f;      // a power of two
+  const float acc_scale = SPLIT ? x_scale / p.split_unscale : 1.0f;      // a power of two: (weight scale) x (activation scale)
+  const float acc_unscale = SPLIT ? p.split_unscale * x_unscale : 1.0f;
   auto init_combine = [&]() {
     f32x16 v;
 #pragma unroll
@@ -261,23 +271,17 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
       const int n = 8 * g4 + 4 * fh;                                                                 \
       u32x4 pk;                                                                                      \
       float v0 = acc[4 * g4], v1 = acc[4 * g4 + 1], v2 = acc[4 * g4 + 2], v3 = acc[4 * g4 + 3];      \
-      if constexpr (SPLIT) {                                                                         \
-        v0 *= p.split_unscale; v1 *= p.split_unscale; v2 *= p.split_unscale; v3 *= p.split_unscale;  \
-        out_max = fmaxf(fmaxf(out_max, fmaxf(fabsf(v0), fabsf(v1))), fmaxf(fabsf(v2), fabsf(v3)));    \
-      }                                                                                              \
+      if constexpr (SPLIT) { v0 *= acc_unscale; v1 *= acc_unscale; v2 *= acc_unscale; v3 *= acc_unscale; } \
       if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); } \
+      if constexpr (SPLIT) out_bits = max(max(out_bits, max(abs_bits(v0), abs_bits(v1))), max(abs_bits(v2), abs_bits(v3))); \
       pk.x = __float_as_uint(v0); pk.y = __float_as_uint(v1); pk.z = __float_as_uint(v2); pk.w = __float_as_uint(v3); \
       __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, (unsigned)(m_ * C + n) * 4u, 0, 0);         \
     }                                                                                                \
   }
-#ifdef UTP_NO_ROTATE
-  const bool late = false;
-#else
   const bool late = ((wave >> 2) & 1) != 0;   // waves w, w+4(, w+8) share a SIMD; wave is uniform (readfirstlane)
-#endif
   bool have_prev = false;
   int prev_m = 0;
-  float out_max = 0.f;      // SPLIT: largest output magnitude of this lane (range guard: the next layer splits it into fp16 pieces)
+  unsigned out_bits = 0;    // SPLIT: bits of the largest output magnitude of this lane (the next layer scales by it before splitting)
   f32x16 ready = init_combine();      // bias + residual of the tile about to be computed
   f32x16 acc;
   for (;;) {
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
   }
   if (late && have_prev) { UTP_EPILOGUE(prev_m); }
   if constexpr (SPLIT) {
-    if (!(out_max < 65504.f) && p.status) atomicOr(p.status, UT_SPLIT_RANGE);
+    if (p.out_max) publish_abs_max(p.out_max, out_bits);
   }
 #undef UTP_EPILOGUE
 }

@@ -10,10 +10,14 @@
 // against the oracle), while the matrix pipe needs 3 x 32 cycles per 16 k instead of 16 x 64 / 2 = 512: 5.3x the rate
 // of v_mfma_f32_32x32x2_f32.  Same layers as conv_igemm.hip (lib/models/backbone_resnet.py:56-72), same NHWC fp32
 // tensors in HBM; only the arithmetic inside the kernel changes.
-// Range: an activation must stay below 65504 in magnitude (fp16's largest finite value; the first piece saturates there
-// and the second takes the rest up to 131008) - post-BatchNorm/ReLU activations of this network are O(1..100).  The
-// weights are pre-scaled per layer by a power of two that puts their largest magnitude just under 2^15, so that the
-// second weight piece of all but vanishing weights is a normal fp16 number; the epilogue multiplies by the inverse.
+// Range: both operands are brought into fp16's range by powers of two, exactly.  The weights are pre-scaled per layer on
+// the host so that their largest magnitude sits just under 2^15; the activations are multiplied, before the split, by the
+// power of two that puts the LAYER's largest activation in [2^14, 2^15) - taken from a device word the producing kernel
+// left (ut_kernels.h::split_act_scale / publish_abs_max), so no host synchronisation.  The first piece then never
+// saturates and the second piece of every value within 2^-18 of the largest is a normal fp16 number; smaller ones keep an
+// absolute error of 2^-40 of the layer's largest activation.  The epilogue multiplies by the inverse of both scales.  The
+// split therefore has fp32's exponent range: a network whose activations are 2^-16 or 2^+16 of this one's gives the same
+// bits (tests/test_gpu_parity.py::test_split_f16_power_of_two_rescale_invariance), like the fp32 kernels.
 //
 // Activations stay fp32 in HBM and in LDS and are split in registers after the fragment read (6 VALU per pair of
 // values: v_cvt_pkrtz_f16_f32, two conversions back, two subtractions, v_cvt_pkrtz_f16_f32); the weights' pieces are made
@@ -159,6 +163,15 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   const u32x4 w_words = rsrc_words(p.w_split, (unsigned)((size_t)(p.cout_pad / 32) * n_chunks * 4096));
   const unsigned smem_addr = (unsigned)(unsigned long)(lds_char*)smem;
 
+  // power-of-two activation scale from the producer's max word, and the epilogue's factor 2^-(weight scale + activation scale)
+  float x_scale = 1.f, x_unscale = 1.f;
+  if (p.in_max) {
+    bool ok;
+    split_act_scale(p.in_max, x_scale, x_unscale, ok);
+    if (!ok && tid == 0 && blockIdx.x == 0 && p.status) atomicOr(p.status, UT_SPLIT_RANGE);
+  }
+  const float tot_unscale = p.split_unscale * x_unscale;
+
   const int grid = gridDim.x;
   int slot = blockIdx.x;
   if ((grid & 7) == 0) slot = (blockIdx.x & 7) * (grid >> 3) + (blockIdx.x >> 3);
@@ -206,7 +219,10 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
     const int sw_ = (row_ >> 1) & 7;                                                                 \
     char* rp_ = smem + (BUF) + row_ * 128;                                                           \
     float4 f_[8];                                                                                    \
-    _Pragma("unroll") for (int g4 = 0; g4 < 8; ++g4) f_[g4] = *reinterpret_cast<const float4*>(rp_ + ((g4 ^ sw_) << 4)); \
+    _Pragma("unroll") for (int g4 = 0; g4 < 8; ++g4) {                                               \
+      f_[g4] = *reinterpret_cast<const float4*>(rp_ + ((g4 ^ sw_) << 4));                            \
+      f_[g4].x *= x_scale; f_[g4].y *= x_scale; f_[g4].z *= x_scale; f_[g4].w *= x_scale;            \
+    }                                                                                                \
     _Pragma("unroll") for (int kg = 0; kg < 4; ++kg) {                                               \
       unsigned a0_, a1_, a2_, a3_, b0_, b1_, b2_, b3_;                                               \
       split_pair(f_[2 * kg].x, f_[2 * kg].y, a0_, b0_);                                              \
@@ -342,8 +358,8 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   {                                                                                                  \
     constexpr int i_ = (U) >> 2, pr_ = (U) & 3;                                                      \
     const float4 v_ = xr[i_][pr_ >> 1];                                                              \
-    if constexpr ((pr_ & 1) == 0) split_pair(v_.x, v_.y, xp[SET][i_][0][pr_], xp[SET][i_][1][pr_]);  \
-    else split_pair(v_.z, v_.w, xp[SET][i_][0][pr_], xp[SET][i_][1][pr_]);                          \
+    if constexpr ((pr_ & 1) == 0) split_pair(v_.x * x_scale, v_.y * x_scale, xp[SET][i_][0][pr_], xp[SET][i_][1][pr_]); \
+    else split_pair(v_.z * x_scale, v_.w * x_scale, xp[SET][i_][0][pr_], xp[SET][i_][1][pr_]);      \
   }
 #define SP_PIN() __builtin_amdgcn_sched_barrier(0)
   // MFMA N of a k-step: products (weight piece, pixel piece) small terms first, accumulators round-robin inside a product
@@ -505,7 +521,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
         }                                                                                            \
     }                                                                                                \
   }
-  float out_max = 0.f;          // largest output magnitude of this lane so far (range guard of the split arithmetic)
+  unsigned out_bits = 0;        // bits of the largest output magnitude of this lane so far (the next layer's activation scale)
   int tile = slot;
   for (;;) {
     const int ticket = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, q_rsrc, q_off, 0, 0);
@@ -585,6 +601,10 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
         for (int g4 = 0; g4 < 4; ++g4)
           bb[j][g4] = *reinterpret_cast<const float4*>(p.bias + tn * BN + wn * (NI * 32) + j * 32 + 8 * g4 + 4 * fh);
       if constexpr (!EARLY_RES) SP_RES_REQUEST();
+      // skip_waits below relies on every transfer issued so far having landed once the epilogue has its operands.  Without
+      // EARLY_RES the residual requests are the youngest operations, so the waits for them say so; with EARLY_RES they went
+      // out in front of the last chunk's transfers: wait for everything here (bias and residual are needed now anyway).
+      if constexpr (EARLY_RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int m = tm * BM + wm * (MI * 32) + i * 32 + fr;
@@ -595,13 +615,13 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
           for (int g4 = 0; g4 < 4; ++g4) {
             const int n = tn * BN + wn * (NI * 32) + j * 32 + 8 * g4 + 4 * fh;
             const unsigned off = (m_ok && n < p.cout_store) ? (unsigned)(m * p.cout_store + n) * 4u : OOB;
+            const unsigned keep = off != OOB ? 0x7FFFFFFFu : 0u;     // rows / channels beyond the tensor do not count
             u32x4 pk;
-            pk.x = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 0], p.split_unscale, bb[j][g4].x + __uint_as_float(rr[i][j][g4].x)), floor_v));
-            pk.y = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 1], p.split_unscale, bb[j][g4].y + __uint_as_float(rr[i][j][g4].y)), floor_v));
-            pk.z = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 2], p.split_unscale, bb[j][g4].z + __uint_as_float(rr[i][j][g4].z)), floor_v));
-            pk.w = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 3], p.split_unscale, bb[j][g4].w + __uint_as_float(rr[i][j][g4].w)), floor_v));
-            out_max = fmaxf(fmaxf(out_max, fmaxf(fabsf(__uint_as_float(pk.x)), fabsf(__uint_as_float(pk.y)))),
-                            fmaxf(fabsf(__uint_as_float(pk.z)), fabsf(__uint_as_float(pk.w))));
+            pk.x = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 0], tot_unscale, bb[j][g4].x + __uint_as_float(rr[i][j][g4].x)), floor_v));
+            pk.y = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 1], tot_unscale, bb[j][g4].y + __uint_as_float(rr[i][j][g4].y)), floor_v));
+            pk.z = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 2], tot_unscale, bb[j][g4].z + __uint_as_float(rr[i][j][g4].z)), floor_v));
+            pk.w = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 3], tot_unscale, bb[j][g4].w + __uint_as_float(rr[i][j][g4].w)), floor_v));
+            out_bits = max(max(out_bits, max(pk.x & keep, pk.y & keep)), max(pk.z & keep, pk.w & keep));
             __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, off, 0, 0);
           }
 #pragma unroll
@@ -610,11 +630,11 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
       }
       skip_waits = 2;
     }
-    if (!(out_max < 65504.f) && p.status) atomicOr(p.status, UT_SPLIT_RANGE);   // (also a NaN): the next layer could not split it
     if (next_tile >= n_tiles) break;
     tile = next_tile;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the transfers issued for tiles that do not exist
+  if (p.out_max) publish_abs_max(p.out_max, out_bits);
 #undef SP_H_SETUP
 #undef SP_H_ISSUE
 #undef SP_H_MASK
@@ -638,7 +658,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
 #undef SP_SIGNAL
 #undef SP_AWAIT
 #undef SP_PEEK
-#undef SP_SLOTS4
+#undef SP_SLOTS3
 #undef SP_STEP
 }
 

@@ -23,7 +23,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void stem_kernel(const T* __restrict__ crops,
                                                    const float* __restrict__ w,
                                                    const float* __restrict__ bias,
-                                                   float* __restrict__ out, int n) {
+                                                   float* __restrict__ out, int n, unsigned* out_max) {
   __shared__ __attribute__((aligned(8))) float tile[IN_ROWS][IN_COLS + 2];   // row stride 100 floats: 8-byte pairs stay aligned
   __shared__ float ws[STEM_C * 9 + STEM_C];
   const int img = blockIdx.y;
@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const T* __restrict__ crops,
     for (int t = 0; t < 9; ++t) wr[k][t] = ws[(cg * 4 + k) * 9 + t];
     br[k] = ws[STEM_C * 9 + cg * 4 + k];
   }
+  unsigned mx = 0;          // bits of this thread's largest output (post-ReLU: non-negative)
   for (int item = threadIdx.x; item < ROWS_PER_WG * POOLED * 8; item += 256) {
     const int pix = item >> 3;
     const int pr = pix / POOLED, pc = pix - pr * POOLED;
@@ -76,28 +77,42 @@ __global__ __launch_bounds__(256) void stem_kernel(const T* __restrict__ crops,
     }
     float* o = out + (((size_t)img * POOLED + prow0 + pr) * POOLED + pc) * STEM_C + cg * 4;
     *reinterpret_cast<float4*>(o) = make_float4(res[0], res[1], res[2], res[3]);
+    const unsigned m01 = max(abs_bits(res[0]), abs_bits(res[1])), m23 = max(abs_bits(res[2]), abs_bits(res[3]));
+    mx = max(mx, max(m01, m23));
   }
+  // the first layer1 convolution may split these activations into fp16 pieces: it scales them by this word (ut_kernels.h)
+  if (out_max) publish_abs_max(out_max, mx);
 }
 
 template <typename T>
-static hipError_t launch_stem_t(const T* crops, const float* w, const float* bias, float* out, int n, hipStream_t s) {
+static hipError_t launch_stem_t(const T* crops, const float* w, const float* bias, float* out, int n, unsigned* out_max,
+                                hipStream_t s) {
   if (n <= 0) return hipSuccess;
   // grid.y is limited to 65535: split very large batches
   for (int done = 0; done < n;) {
     int cnt = n - done < 32768 ? n - done : 32768;
     hipLaunchKernelGGL(stem_kernel<T>, dim3(POOLED / ROWS_PER_WG, cnt), dim3(256), 0, s,
                        crops + (size_t)done * CROP * CROP, w, bias,
-                       out + (size_t)done * POOLED * POOLED * STEM_C, cnt);
+                       out + (size_t)done * POOLED * POOLED * STEM_C, cnt, out_max);
     done += cnt;
   }
   return hipGetLastError();
 }
 
-hipError_t launch_stem(const float* crops, const float* w, const float* bias, float* out, int n, hipStream_t s) {
-  return launch_stem_t(crops, w, bias, out, n, s);
+hipError_t launch_stem(const float* crops, const float* w, const float* bias, float* out, int n, unsigned* out_max,
+                       hipStream_t s) {
+  return launch_stem_t(crops, w, bias, out, n, out_max, s);
 }
-hipError_t launch_stem_u8(const uint8_t* crops, const float* w, const float* bias, float* out, int n, hipStream_t s) {
-  return launch_stem_t(crops, w, bias, out, n, s);
+hipError_t launch_stem_u8(const uint8_t* crops, const float* w, const float* bias, float* out, int n, unsigned* out_max,
+                          hipStream_t s) {
+  return launch_stem_t(crops, w, bias, out, n, out_max, s);
+}
+
+__global__ void merge_max_kernel(unsigned* dst, const unsigned* src) { atomicMax(dst, *src); }
+
+hipError_t launch_merge_max(unsigned* dst, const unsigned* src, hipStream_t s) {
+  hipLaunchKernelGGL(merge_max_kernel, dim3(1), dim3(1), 0, s, dst, src);
+  return hipGetLastError();
 }
 
 }  // namespace ut

@@ -80,9 +80,12 @@ struct ut_context {
   // temporal state
   int slots_cap = 0, slots_used = 0;
   float *mem = nullptr, *prev_ext = nullptr;
-  // tile-queue counters: one word per conv launch of a call, zeroed by one memset at the start of the call
+  // per-launch device words, zeroed by one memset at the start of a call: [i] the tile queue of launch i of the call,
+  // [kMaxCounters + i] the bits of the largest magnitude that launch stored (the activation scale of a split-fp16 consumer)
   unsigned* counters = nullptr;
   int counter_next = 0;
+  unsigned word_gen = 0;            // bumped by every zeroing of the words: a max word kept across launches is stale after it
+  bool call_split = false;          // the running backbone call uses the split-fp16 kernels (decided once per call)
   // index checks: device status words ([0] sticky errors, [1] per call), their pinned host mirror, the duplicate-slot
   // scratch (slots_cap ints, allocated with the temporal state) and the mode (UT_CHECK_*)
   int* status = nullptr;
@@ -178,7 +181,7 @@ int stateless_status(int* device_out, DevStatus* out) {
 
 const char* status_message(int bits) {
   if (bits & ut::UT_SPLIT_RANGE)
-    return "range check: an activation of the split-fp16 backbone reached |x| >= 65504, beyond what two fp16 pieces hold: use UT_CONV_FP32";
+    return "range check: an activation entering a split-fp16 convolution is an infinity or a NaN (the layer has no finite scale)";
   if (bits & ut::UT_BAD_SRC_INDEX) return "index check: src_index outside [0, n_src_images)";
   if (bits & ut::UT_BAD_SAMPLE_RANGE) return "index check: sample_range rows must select 1 or 2 crops inside [0, n_crops]";
   if (bits & ut::UT_BAD_MEMORY_IDX) return "index check: memory_idx outside [0, n_slots)";
@@ -398,15 +401,29 @@ int ensure_slots(ut_handle h, int slots, hipStream_t s) {
 
 constexpr int kMaxCounters = 4096;
 
-// zero the tile-queue words used by the conv launches of one API call (stream ordered)
+// zero the per-launch words (tile queues, output maxima) used by the launches of one API call (stream ordered)
 int begin_call(ut_handle h, hipStream_t s) {
   h->counter_next = 0;
-  HIPCHK(h, hipMemsetAsync(h->counters, 0, kMaxCounters * sizeof(unsigned), s));
+  ++h->word_gen;
+  HIPCHK(h, hipMemsetAsync(h->counters, 0, 2 * kMaxCounters * sizeof(unsigned), s));
   return UT_OK;
 }
 
+// the next launch's index into the per-launch words
+int next_launch_word(ut_handle h, hipStream_t s, int* idx) {
+  if (h->counter_next >= kMaxCounters) {   // recycle: stream order puts the memset behind the earlier launches
+    int rc0 = begin_call(h, s);
+    if (rc0) return rc0;
+  }
+  *idx = h->counter_next++;
+  return UT_OK;
+}
+
+// in_max: the max word of the launch that produced `in` (null: unknown - the launch then stays on the fp32 instruction);
+// *out_max (optional): receives this launch's max word when it ran a kernel that leaves one, else null
 int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, float* out, int n_img, int H, int W,
-             bool relu, bool nchw, hipStream_t s) {
+             bool relu, bool nchw, hipStream_t s, const unsigned* in_max = nullptr, unsigned** out_max = nullptr) {
+  if (out_max) *out_max = nullptr;
   ut::ConvLaunch c{};
   c.in = in; c.w = cw.w; c.bias = cw.bias; c.res = res; c.out = out;
   c.n_img = n_img; c.H = H; c.W = W; c.cin = cw.cin_pad;
@@ -417,11 +434,14 @@ int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, fl
   c.ksize = cw.ksize; c.stride = cw.stride; c.pad = cw.pad;
   c.relu = relu; c.out_nchw = nchw;
   c.device = h->device; c.num_cu = h->num_cu;
-  if (h->counter_next >= kMaxCounters) {   // recycle: stream order puts the memset behind the earlier launches
-    int rc0 = begin_call(h, s);
+  int word = 0;
+  {
+    const unsigned gen = h->word_gen;
+    int rc0 = next_launch_word(h, s, &word);
     if (rc0) return rc0;
+    if (gen != h->word_gen) in_max = nullptr;      // recycled in mid-call: the producer's word has just been zeroed
   }
-  c.tile_counter = h->counters + h->counter_next++;
+  c.tile_counter = h->counters + word;
   // Latency mode: a convolution of a few crops has far fewer 64x64 tiles than the chip has CUs and every workgroup
   // walks all of K alone (a layer-4 conv of 4 crops: 12 tiles x 72 chunks).  Cut K into S equal chunk ranges (S the
   // largest divisor of the chunk count that leaves >= 6 chunks per range and <= one workgroup per CU), let S x tiles
@@ -451,14 +471,17 @@ int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, fl
     pe.flops = cw.flops_per_pixel * (double)n_img * c.Ho * c.Wo;
     HIPCHK(h, hipEventRecord(pe.a, s));
   }
-  // split-fp16 arithmetic: launches that fill the chip with 256-row tiles (the batched backbone); everything else - and
-  // every launch in latency mode - stays on the fp32 matrix instructions
-  const long tiles256 = (((long)n_img * c.Ho * c.Wo + 255) / 256) * ((cw.cout_store + 127) / 128);
-  const bool split = h->conv_arith == UT_CONV_SPLIT_F16_ALWAYS || (h->conv_arith == UT_CONV_SPLIT_F16 && tiles256 >= 2l * h->num_cu);
-  c.w_split = split && !h->latency_mode ? cw.w_split : nullptr;
+  // split-fp16 arithmetic: decided once per backbone call (run_backbone), for every eligible layer of the call whose
+  // producer left a max word; everything else - the head, and every launch in latency mode - stays on the fp32 instruction
+  c.w_split = h->call_split && in_max && !h->latency_mode ? cw.w_split : nullptr;
   c.split_unscale = cw.split_unscale;
   c.status = h->status;
+  c.in_max = in_max;
   pe.kind = c.w_split && (ut::conv_split_applicable(c) || ut::conv_patch_applicable(c)) ? 1 : 0;
+  if (pe.kind) {
+    c.out_max = h->counters + kMaxCounters + word;
+    if (out_max) *out_max = c.out_max;
+  }
   if (c.w_split && ut::conv_split_applicable(c)) HIPCHK(h, ut::launch_conv_split(c, s));
   else HIPCHK(h, ut::launch_conv_igemm(c, s));
   if (h->profiling) {
@@ -469,17 +492,19 @@ int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, fl
 }
 
 // relu(bn2(conv2(relu(bn1(conv1 x)))) + (downsample(x) | x))   lib/models/backbone_resnet.py:56-72
+// x_max: the max word of x's producer (or null); *y_max (optional): the word of the block's output
 int run_block(ut_handle h, const Block& b, const float* x, float* tmp, float* dsbuf, float* y, int n_img, int H,
-              int W, hipStream_t s) {
+              int W, hipStream_t s, const unsigned* x_max = nullptr, unsigned** y_max = nullptr) {
   int rc;
-  if ((rc = run_conv(h, b.conv1, x, nullptr, tmp, n_img, H, W, true, false, s))) return rc;
+  unsigned* tmp_max = nullptr;
+  if ((rc = run_conv(h, b.conv1, x, nullptr, tmp, n_img, H, W, true, false, s, x_max, &tmp_max))) return rc;
   const int Ho = (H + 2 - 3) / b.conv1.stride + 1, Wo = (W + 2 - 3) / b.conv1.stride + 1;
   const float* res = x;
   if (b.has_ds) {
     if ((rc = run_conv(h, b.ds, x, nullptr, dsbuf, n_img, H, W, false, false, s))) return rc;
     res = dsbuf;
   }
-  return run_conv(h, b.conv2, tmp, res, y, n_img, Ho, Wo, true, false, s);
+  return run_conv(h, b.conv2, tmp, res, y, n_img, Ho, Wo, true, false, s, tmp_max, y_max);
 }
 
 }  // namespace
@@ -515,7 +540,7 @@ int ut_create(int device, const float* blob, size_t n_floats, ut_handle* out) {
       b[o] = (float)(((double)sb[o] - (double)sbn.m[o]) * s + (double)sbn.b[o]);
     }
     if ((rc = upload(h, w, &h->stem_w)) || (rc = upload(h, b, &h->stem_b))) break;
-    { float* cnt = nullptr; if ((rc = dev_alloc(h, &cnt, kMaxCounters))) break; h->counters = (unsigned*)cnt; }
+    { float* cnt = nullptr; if ((rc = dev_alloc(h, &cnt, 2 * kMaxCounters))) break; h->counters = (unsigned*)cnt; }
     { float* st = nullptr; if ((rc = dev_alloc(h, &st, 2))) break; h->status = (int*)st;
       hipError_t e2 = hipMemset(h->status, 0, 2 * sizeof(int));
       if (e2 == hipSuccess) e2 = hipHostMalloc((void**)&h->status_host, 2 * sizeof(int), hipHostMallocDefault);
@@ -651,20 +676,34 @@ int ut_warp_crops(ut_handle h, const uint8_t* src, int n_src_images, int src_h, 
   return UT_OK;
 }
 
+// stem launch; *out_max receives its max word when the call runs the split-fp16 kernels
+static int run_stem(ut_handle h, const float* crops, const uint8_t* crops_u8, float* out, int n, hipStream_t st,
+                    unsigned** out_max) {
+  *out_max = nullptr;
+  if (h->call_split && !h->latency_mode) {
+    int word = 0, rc = next_launch_word(h, st, &word);
+    if (rc) return rc;
+    *out_max = h->counters + kMaxCounters + word;
+  }
+  if (crops_u8) HIPCHK(h, ut::launch_stem_u8(crops_u8, h->stem_w, h->stem_b, out, n, *out_max, st));
+  else HIPCHK(h, ut::launch_stem(crops, h->stem_w, h->stem_b, out, n, *out_max, st));
+  return UT_OK;
+}
+
 // stem .. projection over crops given as fp32 (crops) or as u8 grey levels (crops_u8)
 // One sub-batch of n crops (workspace slices starting at crop `off`) through stem .. projection on stream st.
 static int backbone_pass(ut_handle h, const float* crops, const uint8_t* crops_u8, int off, int n, float* feat,
                          hipStream_t st) {
   int rc;
   const size_t a48 = (size_t)off * 48 * 48 * 32, a24 = (size_t)off * 24 * 24 * 64, a12 = (size_t)off * 12 * 12 * 128;
-  if (crops_u8) HIPCHK(h, ut::launch_stem_u8(crops_u8, h->stem_w, h->stem_b, h->bufX + a48, n, st));
-  else HIPCHK(h, ut::launch_stem(crops, h->stem_w, h->stem_b, h->bufX + a48, n, st));
+  unsigned* xm = nullptr;            // max word of the running activation
+  if ((rc = run_stem(h, crops, crops_u8, h->bufX + a48, n, st, &xm))) return rc;
   {
     float *x = h->bufX + a48, *y = h->bufY + a48;
     int hw = 48;
     for (int b = 0; b < 5; ++b) {
       float* dst = b == 4 ? h->bufL2 + a24 : y;
-      if ((rc = run_block(h, h->bb[b], x, h->bufH + a48, h->bufD + a24, dst, n, hw, hw, st))) return rc;
+      if ((rc = run_block(h, h->bb[b], x, h->bufH + a48, h->bufD + a24, dst, n, hw, hw, st, xm, &xm))) return rc;
       hw = (hw + 2 - 3) / h->bb[b].conv1.stride + 1;
       float* t = x; x = y; y = t;
     }
@@ -673,7 +712,7 @@ static int backbone_pass(ut_handle h, const float* crops, const uint8_t* crops_u
   float *y = h->bufP + a12, *other = h->bufQ + a12;
   int hw = 24;
   for (int b = 5; b < 12; ++b) {
-    if ((rc = run_block(h, h->bb[b], x, h->bufBH + a12, h->bufBD + a12, y, n, hw, hw, st))) return rc;
+    if ((rc = run_block(h, h->bb[b], x, h->bufBH + a12, h->bufBD + a12, y, n, hw, hw, st, xm, &xm))) return rc;
     hw = (hw + 2 - 3) / h->bb[b].conv1.stride + 1;
     x = y;
     float* t = y; y = other; other = t;
@@ -690,6 +729,9 @@ static int run_backbone(ut_handle h, const float* crops, const uint8_t* crops_u8
   const int pass_b = n_crops < PHASE_B_MAX ? n_crops : PHASE_B_MAX;
   if ((rc = ensure_phase_b_ws(h, pass_b))) return rc;
   if ((rc = begin_call(h, s))) return rc;
+  // One arithmetic per call, for every eligible layer of it: the split-fp16 kernels when the batch fills the chip with
+  // their 256-row tiles down to the 6x6 maps (512 crops = 72 row tiles x 2 column tiles at layer4), else exact fp32.
+  h->call_split = h->conv_arith == UT_CONV_SPLIT_F16_ALWAYS || (h->conv_arith == UT_CONV_SPLIT_F16 && n_crops >= 2 * h->num_cu);
   // ---- two lanes: the batch fits one pass of both phases and is big enough for two full-chip half-batches.  Every
   // launch is a persistent grid that drains a tile queue; its last round leaves workgroup slots idle for up to a tile
   // time (70-140 us of a 1.3 ms launch).  Frames are independent, so the two halves run the same launch sequence on
@@ -720,26 +762,35 @@ static int run_backbone(ut_handle h, const float* crops, const uint8_t* crops_u8
   for (int base = 0; base < n_crops; base += pass_b) {
     const int nb = n_crops - base < pass_b ? n_crops - base : pass_b;
     // ---- phase A: stem + layer1 (48x48x32) + layer2 (24x24x64), `chunk` crops per pass
-    for (int done = 0; done < nb; done += chunk) {
+    // the words of one pass (<= 2 x 22 + 16 launches) come from one zeroing, so that none of them is recycled while live
+    if (h->counter_next + 256 > kMaxCounters && (rc = begin_call(h, s))) return rc;
+    unsigned* l2_max = nullptr;      // max word of bufL2: the passes' words merged when phase A took more than one pass
+    const unsigned l2_gen = h->word_gen;
+    int passes = 0;
+    for (int done = 0; done < nb; done += chunk, ++passes) {
       const int n = nb - done < chunk ? nb - done : chunk;
       const size_t first = (size_t)(base + done) * 96 * 96;
-      if (crops_u8) HIPCHK(h, ut::launch_stem_u8(crops_u8 + first, h->stem_w, h->stem_b, h->bufX, n, s));
-      else HIPCHK(h, ut::launch_stem(crops + first, h->stem_w, h->stem_b, h->bufX, n, s));
+      unsigned* xm = nullptr;
+      if ((rc = run_stem(h, crops ? crops + first : nullptr, crops_u8 ? crops_u8 + first : nullptr, h->bufX, n, s, &xm))) return rc;
       float *x = h->bufX, *y = h->bufY;
       int hw = 48;
       for (int b = 0; b < 5; ++b) {
         float* dst = b == 4 ? h->bufL2 + (size_t)done * 24 * 24 * 64 : y;
-        if ((rc = run_block(h, h->bb[b], x, h->bufH, h->bufD, dst, n, hw, hw, s))) return rc;
+        if ((rc = run_block(h, h->bb[b], x, h->bufH, h->bufD, dst, n, hw, hw, s, xm, &xm))) return rc;
         hw = (hw + 2 - 3) / h->bb[b].conv1.stride + 1;
         float* t = x; x = y; y = t;
       }
+      if (passes == 0) l2_max = xm;
+      else if (l2_max && xm) HIPCHK(h, ut::launch_merge_max(l2_max, xm, s));
+      else l2_max = nullptr;
     }
     // ---- phase B: layer3 (12x12x128) + layer4 (6x6x256) + projection over the whole pass
     const float* x = h->bufL2;
     float *y = h->bufP, *other = h->bufQ;
     int hw = 24;
+    unsigned* xm = l2_gen == h->word_gen ? l2_max : nullptr;
     for (int b = 5; b < 12; ++b) {
-      if ((rc = run_block(h, h->bb[b], x, h->bufBH, h->bufBD, y, nb, hw, hw, s))) return rc;
+      if ((rc = run_block(h, h->bb[b], x, h->bufBH, h->bufBD, y, nb, hw, hw, s, xm, &xm))) return rc;
       hw = (hw + 2 - 3) / h->bb[b].conv1.stride + 1;
       x = y;
       float* t = y; y = other; other = t;
@@ -820,6 +871,7 @@ int ut_fuse_temporal_regress(ut_handle h, const float* feat, const float* intrin
   if ((rc = ensure_head_ws(h, n_samples, n_skel))) return rc;
   if ((rc = ensure_slots(h, n_slots, s))) return rc;
   if ((rc = begin_call(h, s))) return rc;
+  h->call_split = false;             // the head stays on the fp32 matrix instructions
   ut::HeadArgs a{};
   a.feat = feat; a.intrinsics = intrinsics; a.extrinsics = extrinsics; a.sample_range = sample_range;
   a.memory_idx = memory_idx; a.use_memory = use_memory; a.hand_idx = hand_idx; a.n_samples = n_samples;

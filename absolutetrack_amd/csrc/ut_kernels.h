@@ -17,7 +17,10 @@ struct ConvLaunch {
   const float* w;      // [cout_pad][k_pad]
   const void* w_split; // optional: the two fp16 planes of (w * scale) in fragment order (conv_split.hip), or null
   float split_unscale; // 1 / scale of w_split
-  int* status;         // split kernels: sticky status word, UT_SPLIT_RANGE is set when an output leaves the fp16-split range
+  int* status;         // split kernels: sticky status word, UT_SPLIT_RANGE is set when the input holds an infinity or a NaN
+  const unsigned* in_max;   // split kernels: device word with the bits of max |in| (written by the kernel that produced `in`,
+                            // see publish_abs_max): the power-of-two activation scale of the split comes from it
+  unsigned* out_max;        // optional device word (zero before the launch): receives the bits of max |out|
   const float* bias;   // [cout_pad]
   const float* res;    // optional residual, same layout as out
   float* out;          // NHWC [n_img, Ho, Wo, cout_store] or NCHW [n_img, cout_store, Ho*Wo]
@@ -46,15 +49,19 @@ bool conv_split_applicable(const ConvLaunch& c);
 hipError_t launch_conv_split(const ConvLaunch& c, hipStream_t s);
 size_t pack_split_weights(const float* w, int cout_pad, int k_pad, float scale, uint16_t* out);
 float split_weight_scale(const float* w, size_t n);
+// *dst = max(*dst, *src) on two max words (one thread): the activation of several passes read by one consumer
+hipError_t launch_merge_max(unsigned* dst, const unsigned* src, hipStream_t s);
 // 3x3 stride-1 32->32 channel convs with the halo patch resident in LDS (conv_patch.hip)
 bool conv_patch_applicable(const ConvLaunch& c);
 hipError_t launch_conv_patch(const ConvLaunch& c, hipStream_t s);
 
 // stem: conv3x3(1->32,pad 1)+BN+ReLU+maxpool2 ; crops [n,96,96] -> NHWC [n,48,48,32]
+// out_max: optional device word (zero before the launch) that receives the bits of the largest output
 hipError_t launch_stem(const float* crops, const float* w /*[32][9]*/, const float* bias /*[32]*/,
-                       float* out, int n, hipStream_t s);
+                       float* out, int n, unsigned* out_max, hipStream_t s);
 // the same on the resampler's u8 grey levels (value / 255 on load)
-hipError_t launch_stem_u8(const uint8_t* crops, const float* w, const float* bias, float* out, int n, hipStream_t s);
+hipError_t launch_stem_u8(const uint8_t* crops, const float* w, const float* bias, float* out, int n, unsigned* out_max,
+                          hipStream_t s);
 
 struct HeadBuffers {
   // workspace, all NHWC over the 6x6 map: [S,36,C]
@@ -80,9 +87,43 @@ enum : int {
   UT_BAD_HAND_IDX = 8,       // hand_idx not 0 / 1
   UT_SINGLE_VIEW = 16,       // informational: at least one one-view sample (an error only in unknown-skeleton mode)
   UT_BAD_SRC_INDEX = 32,     // ut_warp_crops: src_index outside [0, n_src_images)
-  UT_SPLIT_RANGE = 64,       // split-fp16 convolutions: an activation of magnitude >= 65504 (the next layer could not split it)
+  UT_SPLIT_RANGE = 64,       // split-fp16 convolutions: an input activation is an infinity or a NaN (nothing to scale by)
 };
 constexpr int UT_STATUS_ERRORS = UT_BAD_SAMPLE_RANGE | UT_BAD_MEMORY_IDX | UT_DUP_MEMORY_IDX | UT_BAD_HAND_IDX | UT_BAD_SRC_INDEX | UT_SPLIT_RANGE;
+
+#if defined(__HIPCC__)
+// ---- activation range of the split-fp16 arithmetic -------------------------------------------------------------------
+// Every kernel whose output a split convolution reads leaves the bits of max |out| in a device word (the values are
+// compared as unsigned integers: for non-negative floats that is the float order, an infinity or a NaN compares above
+// every finite value).  The consumer turns the word into a power of two 2^k that puts the largest activation in
+// [2^14, 2^15), multiplies every activation by it before the two-piece split (exact in fp32) and folds 2^-k into the
+// epilogue's factor: the first piece then never saturates and the second stays a normal fp16 number for every activation
+// within 2^-18 of the layer's largest - the split has fp32's exponent range instead of fp16's, with no precondition on
+// the network's activation magnitudes (lib/models/backbone_resnet.py:56-72 has none either).
+__device__ __forceinline__ unsigned abs_bits(float v) { return __float_as_uint(v) & 0x7FFFFFFFu; }
+
+// one relaxed look first: after the first few workgroups the word is near its final value and the atomic is skipped
+__device__ __forceinline__ void publish_abs_max(unsigned* word, unsigned lane_bits) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) {
+    const unsigned other = (unsigned)__shfl_xor((int)lane_bits, o);
+    lane_bits = other > lane_bits ? other : lane_bits;
+  }
+  if ((threadIdx.x & 63) == 0 && lane_bits > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(word, lane_bits);
+}
+
+// scale = 2^k, unscale = 2^-k; ok = false when the word holds an infinity / a NaN (scale 1 then)
+__device__ __forceinline__ void split_act_scale(const unsigned* in_max, float& scale, float& unscale, bool& ok) {
+  const unsigned bits = (unsigned)__builtin_amdgcn_readfirstlane((int)*in_max);
+  const int e = (int)(bits >> 23);
+  ok = e != 255;
+  int k = (bits == 0u || !ok) ? 0 : 141 - e;      // max in [2^(e-127), 2^(e-126)) -> times 2^k in [2^14, 2^15)
+  k = k > 100 ? 100 : k < -100 ? -100 : k;
+  scale = __uint_as_float((unsigned)(127 + k) << 23);
+  unscale = __uint_as_float((unsigned)(127 - k) << 23);
+}
+#endif
 
 struct HeadArgs {
   const float* feat;        // [N,72,36] NCHW

@@ -81,18 +81,27 @@ int ut_poll_status(ut_handle h, void* stream);
  * are bit-identical.  Not applied between ut_profile_begin / ut_profile_end. */
 int ut_set_backbone_lanes(ut_handle h, int lanes);
 
-/* Arithmetic of the batched backbone convolutions (cin % 32 == 0, >= 64 channels out, launches that fill the chip).
+/* Arithmetic of the 3x3 convolutions of the backbone (all 24 of them: layer1 .. layer4; lib/models/backbone_resnet.py:56-72).
  *  UT_CONV_FP32        v_mfma_f32_32x32x2_f32: the exact fp32 multiply-add chain (default).
  *  UT_CONV_SPLIT_F16   both operands as two fp16 pieces (x0 = fp16(x), x1 = fp16(x - x0): 22 significand bits), three
  *                      piece products per k on v_mfma_f32_32x32x16_f16, fp32 accumulation: the terms dropped are ~2^-22
  *                      of a product, so the result carries fp32-level rounding error (not the fp32 chain's bits: outputs
- *                      agree with UT_CONV_FP32 to ~1e-6 relative) at up to 5.3x the matrix rate.  Precondition:
- *                      |activation| < 65504 (fp16's range; the network's post-BatchNorm activations are O(1..100)),
- *                      checked on the device: an output of a split convolution beyond it sets a sticky status bit
- *                      that the next status read (ut_poll_status, or any call that reads the index checks in
- *                      UT_CHECK_SYNC mode) returns as UT_E_INVALID "range check: ...".
- *  UT_CONV_SPLIT_F16_ALWAYS  the same kernel also for launches too small to fill the chip (slower there: for tests).
- * Every other launch (stem, layer1, 1x1 shortcuts, head, and all launches in latency mode) is unaffected. */
+ *                      agree with UT_CONV_FP32 to ~1e-6 relative) at up to 5.3x the matrix rate.
+ *                      Range: none to respect.  Before the split both operands are multiplied by exact powers of two - the
+ *                      weights per layer on the host, the activations per launch by the power of two that puts the layer's
+ *                      largest activation in [2^14, 2^15), read from a device word the producing kernel leaves (no host
+ *                      synchronisation) - and the result by the inverse.  Activations 2^-16 or 2^+16 of another network's
+ *                      give the same bits, as with fp32; values below 2^-18 of their layer's largest keep an absolute error
+ *                      of 2^-40 of that largest.  Only an infinity or a NaN among a layer's inputs has no scale: it sets a
+ *                      sticky status bit that the next status read (ut_poll_status, or any call that reads the index checks
+ *                      in UT_CHECK_SYNC mode) returns as UT_E_INVALID "range check: ...".
+ *                      The mode is chosen once per ut_backbone / ut_warp_backbone call, for every 3x3 convolution of it:
+ *                      split for calls of >= 2 x (compute units) crops (512 on MI355X: their 256-row tiles then fill the
+ *                      chip down to the 6x6 maps), exact fp32 below.  The activation scale is taken over the whole
+ *                      launch, so in this mode a crop's low-order bits can depend on its batch (at the 1e-7 level).
+ *  UT_CONV_SPLIT_F16_ALWAYS  the same for calls of any size (slower on small ones: for tests).
+ * The stem, the 1x1 shortcut convolutions, the projection, the head, and every launch in latency mode stay on the fp32
+ * instruction in every mode. */
 enum { UT_CONV_FP32 = 0, UT_CONV_SPLIT_F16 = 1, UT_CONV_SPLIT_F16_ALWAYS = 2 };
 int ut_set_conv_arithmetic(ut_handle h, int mode);
 

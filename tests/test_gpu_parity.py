@@ -105,21 +105,90 @@ def test_split_f16_backbone_matches_oracle(engine, split_engine):
     assert torch.equal(split_engine.backbone(_dev(crops)).cpu(), got)       # deterministic
 
 
-def test_split_f16_range_guard():
-    """The split arithmetic holds an activation in two fp16 pieces, i.e. up to |x| < 65504: a network whose activations leave
-    that range (here: one convolution's weights scaled by 1e6) is reported - a sticky device-side flag, raised at the next
-    status read - instead of silently saturating; the exact-fp32 mode runs the same weights without complaint."""
+def _rescaled_state_dict(k: int):
+    """synthetic_state_dict(0) with every backbone block's bn1.{weight,bias} x 2^-k and conv2.weight x 2^k: the activations
+    between conv1 and conv2 of every block are 2^-k of the original network's, everything else - in exact arithmetic and
+    in fp32, where powers of two commute with every rounding and with ReLU - is unchanged."""
     sd = dict(synth.synthetic_state_dict(0))
-    k = "_feature_extractor._image_backbone.0._layers.2.0.conv2.weight"
-    sd[k] = sd[k] * np.float32(1e6)
+    down, up = np.float32(2.0 ** -k), np.float32(2.0 ** k)
+    n = 0
+    for key in list(sd):
+        if "_image_backbone.0._layers." not in key:
+            continue
+        if key.endswith(".bn1.weight") or key.endswith(".bn1.bias"):
+            sd[key] = sd[key] * down
+            n += 1
+        elif key.endswith(".conv2.weight"):
+            sd[key] = sd[key] * up
+            n += 1
+    assert n == 36          # 12 blocks x (bn1.weight, bn1.bias, conv2.weight)
+    return sd
+
+
+@pytest.mark.parametrize("k", [8, 12, 14, 16, 40, -8, -14, -16, -40])
+def test_split_f16_power_of_two_rescale_invariance(engine, split_engine, k):
+    """fp32 `relu(bn(conv))` (lib/models/backbone_resnet.py:56-72) has no range precondition: a network whose inner
+    activations are 2^-k (or 2^+k: far beyond fp16's 65504) of another's gives the same bits.  The split-fp16 kernels scale
+    every layer's activations by a power of two taken from the producer's max word before the two-piece split, so they
+    inherit that: identical features whatever k, and the reference's own golden outputs at the path's tolerances."""
+    crops = _dev(synth.synthetic_crops(7, seed=3))
+    base32, base_split = engine.backbone(crops), split_engine.backbone(crops)
+    eng = _native.HipEngine(_rescaled_state_dict(k), DEV)
+    try:
+        assert torch.equal(eng.backbone(crops), base32)                    # the fp32 kernels: bit for bit
+        eng.set_conv_arithmetic("split_f16_always")
+        got = eng.backbone(crops)
+        eng.poll_status()                                                  # nothing to report at any k
+        scale = max(1.0, base32.abs().max().item())
+        assert (got - base32).abs().max().item() < 1e-5 * scale            # split vs fp32: as for the unscaled network
+        assert torch.equal(got, base_split)                                # and the same bits as the unscaled split run
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("known", [True, False])
+@pytest.mark.parametrize("k", [14, -16])
+def test_split_f16_rescaled_network_matches_reference_goldens(golden_dir, known, k):
+    """The rescaled networks above through backbone + head against the reference's own outputs (1e-4 rad / 1e-3 mm)."""
+    eng = _native.HipEngine(_rescaled_state_dict(k), DEV)
+    try:
+        eng.set_conv_arithmetic("split_f16_always")
+        test_model_matches_reference_goldens(eng, golden_dir, known)
+        eng.poll_status()
+    finally:
+        eng.close()
+
+
+def test_split_f16_large_activations_and_non_finite_guard(engine):
+    """One convolution's weights x 1e6 puts its block's activations at ~1e6-1e8, far beyond fp16's 65504: the split mode
+    scales them into range and agrees with the exact-fp32 mode on the same weights to fp32-level relative error.  What has no
+    scale is an infinity or a NaN among a layer's inputs: a sticky device-side flag, raised at the next status read; the
+    exact-fp32 mode runs the same weights without complaint (it propagates the infinity like the reference)."""
+    sd = dict(synth.synthetic_state_dict(0))
+    key = "_feature_extractor._image_backbone.0._layers.2.0.conv2.weight"
+    sd[key] = sd[key] * np.float32(1e6)
     crops = _dev(synth.synthetic_crops(6, seed=4))
+    eng = _native.HipEngine(sd, DEV)
+    try:
+        want = eng.backbone(crops)
+        eng.set_conv_arithmetic("split_f16_always")
+        got = eng.backbone(crops)
+        eng.poll_status()
+        assert torch.isfinite(got).all()
+        assert (got - want).abs().max().item() < 1e-5 * max(1.0, want.abs().max().item())
+    finally:
+        eng.close()
+    sd = dict(synth.synthetic_state_dict(0))
+    key = "_feature_extractor._image_backbone.0._layers.2.0.bn2.bias"
+    sd[key] = sd[key].copy()
+    sd[key][3] = np.float32(np.inf)
     eng = _native.HipEngine(sd, DEV)
     try:
         eng.backbone(crops)
         eng.poll_status()                                   # fp32 mode: nothing to report
         eng.set_conv_arithmetic("split_f16_always")
         eng.backbone(crops)
-        with pytest.raises(FloatingPointError, match="65504"):
+        with pytest.raises(FloatingPointError, match="infinity or a NaN"):
             eng.poll_status()
         eng.poll_status()                                   # the flag was cleared by the read that reported it
     finally:
