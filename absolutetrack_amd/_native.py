@@ -4,6 +4,7 @@ There is no CPU fallback: if the shared library is missing or no HIP device is
 present, every entry point raises.  PyTorch-ROCm is used for device memory and
 streams only; tensors cross the boundary as raw device pointers.
 """
+import contextlib
 import ctypes
 import os
 from typing import Dict, Optional, Tuple
@@ -22,7 +23,7 @@ EXPORTS = (
     "ut_reset_memory", "ut_get_memory", "ut_fk", "ut_gen_crop_cameras", "ut_gen_crop_matrices",
     "ut_resample_homography", "ut_keypoint_metrics", "ut_profile_begin", "ut_profile_end", "ut_profile_end_by_kind",
     "ut_set_index_checks", "ut_poll_status", "ut_warp_backbone", "ut_set_latency_mode", "ut_set_conv_arithmetic",
-    "ut_set_backbone_lanes",
+    "ut_set_backbone_lanes", "ut_status_snapshot", "ut_warp_map",
 )
 
 UT_MODE_KNOWN, UT_MODE_UNKNOWN = 0, 1
@@ -96,6 +97,10 @@ def load_library() -> ctypes.CDLL:
     lib.ut_set_index_checks.argtypes = [vp, i32]
     lib.ut_set_backbone_lanes.restype = i32
     lib.ut_set_backbone_lanes.argtypes = [vp, i32]
+    lib.ut_warp_map.restype = i32
+    lib.ut_warp_map.argtypes = [vp, vp, vp, i32, i32, vp, vp]
+    lib.ut_status_snapshot.restype = i32
+    lib.ut_status_snapshot.argtypes = [vp, vp, vp]
     lib.ut_set_latency_mode.restype = i32
     lib.ut_set_latency_mode.argtypes = [vp, i32]
     lib.ut_set_conv_arithmetic.restype = i32
@@ -317,6 +322,26 @@ def keypoint_metrics(gt: torch.Tensor, tracked: torch.Tensor, valid: torch.Tenso
     return out
 
 
+def warp_map(cam_params: torch.Tensor, crop_params: torch.Tensor, src_index: torch.Tensor, n_src_images: int) -> torch.Tensor:
+    """ut_warp_map: the fp32 coordinate maps [n_crops,96,96,2] (x, y) the resampler samples with (what the reference hands to
+    cv2.remap, lib/tracker/tracker.py:69-85)."""
+    lib = load_library()
+    d = cam_params.device
+    if d.type != "cuda":
+        raise NativeLibraryError("warp_map needs tensors on a HIP device (no CPU fallback)")
+    cam, crop = _need(cam_params, torch.float64, d, "cam_params"), _need(crop_params, torch.float64, d, "crop_params")
+    idx = _need(src_index, torch.int32, d, "src_index")
+    n = crop.shape[0]
+    if crop.shape != (n, 24) or cam.dim() != 2 or cam.shape[1] != 32 or idx.shape != (n,) or cam.shape[0] < n_src_images:
+        raise ValueError("cam_params [n_src,32] f64, crop_params [n,24] f64, src_index [n] i32")
+    out = torch.empty(n, arch.CROP, arch.CROP, 2, device=d)
+    with torch.cuda.device(d):
+        rc = lib.ut_warp_map(_ptr(cam), _ptr(crop), _ptr(idx), int(n_src_images), n, _ptr(out), _stream(d))
+    if rc != 0:
+        raise RuntimeError(f"ut_warp_map failed ({rc}): {lib.ut_last_error(None).decode()}")
+    return out
+
+
 class HipEngine:
     """One native handle (packed weights + workspace + temporal state) on one GPU."""
 
@@ -335,6 +360,8 @@ class HipEngine:
         if rc != 0:
             raise RuntimeError(f"ut_create failed ({rc}): {self.lib.ut_last_error(None).decode()}")
         self._h = h
+        self.deferred_checks = False      # mirrors of the handle's modes (the C ABI has setters only)
+        self.latency_mode = False
 
     def close(self):
         if getattr(self, "_h", None):
@@ -365,6 +392,32 @@ class HipEngine:
         the device and `poll_status()` raises for it later."""
         self._check(self.lib.ut_set_index_checks(self._h, UT_CHECK_DEFERRED if deferred else UT_CHECK_SYNC),
                     "ut_set_index_checks")
+        self.deferred_checks = bool(deferred)
+
+    @contextlib.contextmanager
+    def modes(self, deferred_checks: Optional[bool] = None, latency: Optional[bool] = None):
+        """Switch the handle's check / latency mode for the calls inside the `with` block and put back what was set
+        before: a handle shared by a per-frame HandTracker (latency mode, deferred checks) and a batched HotPath keeps
+        each user's settings out of the other's calls."""
+        prev = (self.deferred_checks, self.latency_mode)
+        try:
+            if deferred_checks is not None and deferred_checks != prev[0]:
+                self.set_index_checks(deferred_checks)
+            if latency is not None and latency != prev[1]:
+                self.set_latency_mode(latency)
+            yield self
+        finally:
+            if self._h:
+                if self.deferred_checks != prev[0]:
+                    self.set_index_checks(prev[0])
+                if self.latency_mode != prev[1]:
+                    self.set_latency_mode(prev[1])
+
+    def status_snapshot(self, out: torch.Tensor):
+        """Stream-ordered copy of the two device status words (sticky errors, this call's bits) into `out` (int32 [2] on
+        the device) - for callers that read results back in one staged transfer and look at the verdict there."""
+        out = _need(out, torch.int32, self.device, "out")
+        self._check(self.lib.ut_status_snapshot(self._h, _ptr(out), _stream(self.device)), "ut_status_snapshot")
 
     def set_backbone_lanes(self, lanes: int):
         """2: large batches run as two half-batches on two internal streams (each fills the other's launch tails)."""
@@ -374,6 +427,7 @@ class HipEngine:
         """Few-crop launches split K across workgroups (per-frame tracking); results then agree with the default mode to
         fp32 rounding instead of bit for bit.  Off by default."""
         self._check(self.lib.ut_set_latency_mode(self._h, int(bool(on))), "ut_set_latency_mode")
+        self.latency_mode = bool(on)
 
     def set_conv_arithmetic(self, mode: str):
         """"fp32": exact fp32 matrix instructions (default).  "split_f16": the batched backbone convolutions run on the fp16

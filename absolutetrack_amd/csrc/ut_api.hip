@@ -676,6 +676,15 @@ int ut_warp_crops(ut_handle h, const uint8_t* src, int n_src_images, int src_h, 
   return UT_OK;
 }
 
+extern "C" int ut_warp_map(const double* cam_params, const double* crop_params, const int32_t* src_index, int n_src_images,
+                           int n_crops, float* out_map, void* stream) {
+  if (n_crops == 0) return UT_OK;
+  if (!cam_params || !crop_params || !src_index || !out_map || n_crops < 0 || n_src_images <= 0)
+    return fail(nullptr, UT_E_INVALID, "ut_warp_map: bad argument");
+  HIPCHK(nullptr, ut::launch_warp_map(cam_params, crop_params, src_index, n_src_images, n_crops, out_map, (hipStream_t)stream));
+  return UT_OK;
+}
+
 // stem launch; *out_max receives its max word when the call runs the split-fp16 kernels
 static int run_stem(ut_handle h, const float* crops, const uint8_t* crops_u8, float* out, int n, hipStream_t st,
                     unsigned** out_max) {
@@ -1060,6 +1069,13 @@ int ut_poll_status(ut_handle h, void* stream) {
     snprintf(buf, sizeof buf, "reported late (deferred checks): %s", status_message(sticky));
     return fail(h, UT_E_INVALID, buf);
   }
+  return UT_OK;
+}
+
+int ut_status_snapshot(ut_handle h, int32_t* dst, void* stream) {
+  if (!h || !dst) return fail(h, UT_E_INVALID, "ut_status_snapshot: null argument");
+  ON_DEVICE_OF(h);
+  HIPCHK(h, hipMemcpyAsync(dst, h->status, 2 * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return UT_OK;
 }
 

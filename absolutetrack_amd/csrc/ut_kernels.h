@@ -216,4 +216,8 @@ hipError_t launch_warp(const uint8_t* src, int n_src, int src_h, int src_w, cons
                        const double* crop, const int32_t* src_index, int n_crops, int mode, float* out,
                        uint8_t* out_u8, int* status, hipStream_t s);
 
+// diagnostic: the fp32 coordinate map of every crop, [n_crops, 96, 96, 2] (x, y); a bad src_index gives (-1, -1)
+hipError_t launch_warp_map(const double* cam, const double* crop, const int32_t* src_index, int n_src, int n_crops,
+                           float* out, hipStream_t s);
+
 }  // namespace ut

@@ -16,26 +16,9 @@ __device__ inline int tap(const uint8_t* img, int h, int w, int x, int y) {
   return (x >= 0 && x < w && y >= 0 && y < h) ? (int)img[y * w + x] : 0;
 }
 
-template <bool U8>
-__global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ src, int src_h, int src_w,
-                                                   const double* __restrict__ cam,
-                                                   const double* __restrict__ crop,
-                                                   const int32_t* __restrict__ src_index, int n_src, int mode,
-                                                   float* __restrict__ out, uint8_t* __restrict__ out_u8,
-                                                   int* __restrict__ status) {
-  const int ci = blockIdx.y;
-  const int pix = blockIdx.x * 256 + threadIdx.x;
-  if (pix >= CROP_PX) return;
-  const int si = src_index[ci];
-  if (si < 0 || si >= n_src) {      // the reference would raise IndexError on views[cam_idx] (lib/tracker/tracker.py:330)
-    if constexpr (U8) out_u8[(size_t)ci * CROP_PX + pix] = 0;
-    else out[(size_t)ci * CROP_PX + pix] = 0.f;
-    if (pix == 0) atomicOr(status, UT_BAD_SRC_INDEX);
-    return;
-  }
-  const double* cp = crop + (size_t)ci * 24;
-  const double* sp = cam + (size_t)si * 32;
-  const int px = pix % 96, py = pix / 96;
+// the fp32 source window coordinates of destination pixel (px, py): lib/tracker/tracker.py:69-82
+__device__ __forceinline__ void warp_coords(const double* __restrict__ cp, const double* __restrict__ sp, int px, int py,
+                                            float& mx, float& my) {
   // crop pinhole: unproject to a unit ray (camera.py:69-75, affine.py:22-24)
   double qx = ((double)px - cp[2]) / cp[0], qy = ((double)py - cp[3]) / cp[1];
   double nrm = fmax(5.43e-20, sqrt(qx * qx + qy * qy + 1.0));
@@ -69,7 +52,40 @@ __global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ s
   double yd = y + (2 * p1 * xy + p2 * (rr + 2 * y2));
   double mxd = xd * sp[0] + sp[2], myd = yd * sp[1] + sp[3];
   if (ez < 0) { mxd = -1.0; myd = -1.0; }      // tracker.py:78-80
-  const float mx = (float)mxd, my = (float)myd;  // tracker.py:82
+  mx = (float)mxd; my = (float)myd;            // tracker.py:82
+}
+
+// diagnostic entry (ut_warp_map): the coordinate map itself, [n_crops, 96, 96, 2] fp32 (x, y)
+__global__ __launch_bounds__(256) void warp_map_kernel(const double* __restrict__ cam, const double* __restrict__ crop,
+                                                       const int32_t* __restrict__ src_index, int n_src,
+                                                       float* __restrict__ out) {
+  const int ci = blockIdx.y;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int si = src_index[ci];
+  float mx = -1.f, my = -1.f;
+  if (si >= 0 && si < n_src) warp_coords(crop + (size_t)ci * 24, cam + (size_t)si * 32, pix % 96, pix / 96, mx, my);
+  reinterpret_cast<float2*>(out)[(size_t)ci * CROP_PX + pix] = make_float2(mx, my);
+}
+
+template <bool U8>
+__global__ __launch_bounds__(256) void warp_kernel(const uint8_t* __restrict__ src, int src_h, int src_w,
+                                                   const double* __restrict__ cam,
+                                                   const double* __restrict__ crop,
+                                                   const int32_t* __restrict__ src_index, int n_src, int mode,
+                                                   float* __restrict__ out, uint8_t* __restrict__ out_u8,
+                                                   int* __restrict__ status) {
+  const int ci = blockIdx.y;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= CROP_PX) return;
+  const int si = src_index[ci];
+  if (si < 0 || si >= n_src) {      // the reference would raise IndexError on views[cam_idx] (lib/tracker/tracker.py:330)
+    if constexpr (U8) out_u8[(size_t)ci * CROP_PX + pix] = 0;
+    else out[(size_t)ci * CROP_PX + pix] = 0.f;
+    if (pix == 0) atomicOr(status, UT_BAD_SRC_INDEX);
+    return;
+  }
+  float mx, my;
+  warp_coords(crop + (size_t)ci * 24, cam + (size_t)si * 32, pix % 96, pix / 96, mx, my);
   const uint8_t* img = src + (size_t)si * src_h * src_w;
   float result;
   if (mode == 0) {
@@ -112,6 +128,17 @@ hipError_t launch_warp(const uint8_t* src, int n_src, int src_h, int src_w, cons
       hipLaunchKernelGGL(warp_kernel<false>, dim3(CROP_PX / 256, cnt), dim3(256), 0, s, src, src_h, src_w, cam,
                          crop + (size_t)done * 24, src_index + done, n_src, mode, out + (size_t)done * CROP_PX,
                          (uint8_t*)nullptr, status);
+    done += cnt;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_warp_map(const double* cam, const double* crop, const int32_t* src_index, int n_src, int n_crops,
+                           float* out, hipStream_t s) {
+  for (int done = 0; done < n_crops;) {
+    int cnt = n_crops - done < 32768 ? n_crops - done : 32768;
+    hipLaunchKernelGGL(warp_map_kernel, dim3(CROP_PX / 256, cnt), dim3(256), 0, s, cam, crop + (size_t)done * 24,
+                       src_index + done, n_src, out + (size_t)done * CROP_PX * 2);
     done += cnt;
   }
   return hipGetLastError();

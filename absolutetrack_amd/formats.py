@@ -220,9 +220,11 @@ class TorchIdx:
         return int(self._byte_offsets[len(self) if i == -1 else i])
 
     def byte_offsets(self, start: int, end: int) -> np.ndarray:
-        """Byte offsets of frames start..end-1 (`end` may be N+1 or -1: one past the last frame's start), the span
-        form the reference's async reader asks for (lib/data_utils/idxbinfile.py:213-231)."""
-        return self._byte_offsets[start: len(self) + 1 if end == -1 else end]
+        """Byte offsets of frames start..end-1, the span form the reference's async reader asks for
+        (lib/data_utils/idxbinfile.py:213-231): `end` may be N+1 (the end-of-data offset included); `end == -1` stops
+        BEFORE the end-of-data offset like the reference does on both of its branches (`array[start:-1]`, and
+        `arange(start, N)`): N - start entries."""
+        return self._byte_offsets[start: len(self) if end == -1 else end]
 
     def data_size_bytes(self) -> int:
         return self.byte_offset(-1) - self.byte_offset(0)

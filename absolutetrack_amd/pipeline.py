@@ -239,9 +239,10 @@ def make_batch(plan: dict, src_u8: torch.Tensor, device, independent_frames: boo
 class HotPath:
     """warp -> backbone -> fuse/temporal/regress -> FK over one FrameBatch; all buffers preallocated.
 
-    The engine's index checks run deferred (no stream synchronisation inside `step`, so the host keeps launching
-    ahead of the GPU): a bad index tensor makes the device skip that call's work, and `check()` - call it wherever the
-    records are consumed - raises IndexError for it."""
+    Inside `step` the engine's index checks run deferred (no stream synchronisation, so the host keeps launching ahead
+    of the GPU) and its latency mode is off; both settings are put back at the end of the step, so the handle can be
+    shared with a per-frame HandTracker.  A bad index tensor makes the device skip that call's work, and `check()` - call
+    it wherever the records are consumed - raises IndexError for it."""
 
     def __init__(self, engine: _native.HipEngine, hand_model_mm: HandModel, known_skeleton: bool = True,
                  remap_mode: int = _native.UT_REMAP_CV2_FIXED, keep_crops: bool = False):
@@ -249,7 +250,6 @@ class HotPath:
         `self.crops`) instead of the fused ut_warp_backbone, whose crops stay u8 in the engine's workspace."""
         self.engine = engine
         self.keep_crops = keep_crops
-        engine.set_index_checks(deferred=True)
         self.mode = _native.UT_MODE_KNOWN if known_skeleton else _native.UT_MODE_UNKNOWN
         self.remap_mode = remap_mode
         dev = engine.device
@@ -276,18 +276,19 @@ class HotPath:
         """[S,123] records (pose record | keypoints in mm)."""
         eng = self.engine
         crops, feat, rec = self._buffers(b)
-        if self.keep_crops:
-            eng.warp_crops(b.src, b.cam_params, b.crop_params, b.src_index, self.remap_mode, out=crops)
-            eng.backbone(crops, out=feat)
-        else:
-            eng.warp_backbone(b.src, b.cam_params, b.crop_params, b.src_index, self.remap_mode, out=feat)
-        s = b.n_samples
-        pose, _ = eng.fuse_temporal_regress(feat, b.intrinsics, b.extrinsics, b.sample_range, b.memory_idx,
-                                            b.use_memory, b.hand_idx, b.n_slots, b.all_multiview, self.skel,
-                                            self.mode, out=self._pose_buf(s))
-        # FK consumes the pose records in place (row stride 60): metres -> mm, right hands un-mirrored
-        kp = eng.fk(self.hand_blob, pose, pose[:, 22:], mirror=b.hand_idx, t_scale=1000.0,
-                    ja_stride=arch.POSE_REC, xf_stride=arch.POSE_REC, n=s, out=self._kp_buf(s))
+        with eng.modes(deferred_checks=True, latency=False):
+            if self.keep_crops:
+                eng.warp_crops(b.src, b.cam_params, b.crop_params, b.src_index, self.remap_mode, out=crops)
+                eng.backbone(crops, out=feat)
+            else:
+                eng.warp_backbone(b.src, b.cam_params, b.crop_params, b.src_index, self.remap_mode, out=feat)
+            s = b.n_samples
+            pose, _ = eng.fuse_temporal_regress(feat, b.intrinsics, b.extrinsics, b.sample_range, b.memory_idx,
+                                                b.use_memory, b.hand_idx, b.n_slots, b.all_multiview, self.skel,
+                                                self.mode, out=self._pose_buf(s))
+            # FK consumes the pose records in place (row stride 60): metres -> mm, right hands un-mirrored
+            kp = eng.fk(self.hand_blob, pose, pose[:, 22:], mirror=b.hand_idx, t_scale=1000.0,
+                        ja_stride=arch.POSE_REC, xf_stride=arch.POSE_REC, n=s, out=self._kp_buf(s))
         rec[:, : arch.POSE_REC].copy_(pose)
         rec[:, arch.POSE_REC:].copy_(kp.reshape(s, -1))
         return rec
@@ -313,6 +314,25 @@ def shard_frames(n_frames_total: int, rank: int, world: int) -> Tuple[int, int]:
     base, extra = divmod(n_frames_total, world)
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_sequences(n_sequences_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Sequence mode (temporal memory engaged): the unit that shards is the SEQUENCE, not the frame.  Rank `rank` owns
+    the contiguous block [lo, hi) of sequences for every time step, so a hand-sequence's temporal slot
+    (`_mem_features[memory_idx]`, lib/models/temporal.py:101-137) lives on one rank for its whole life and no state ever
+    crosses ranks; the records of a step are gathered in sequence order by `gather_records` like frame shards are.
+    Mirrors the reference's only distribution idiom, `indices[rank::world_size]` (lib/data_utils/async_dataset.py:546-559),
+    but contiguous to keep output order (SURVEY.md section 8 e)."""
+    return shard_frames(n_sequences_total, rank, world)
+
+
+def sequence_step_descriptors(hand_idx: torch.Tensor, first_step: bool) -> Tuple[torch.Tensor, torch.Tensor, int]:
+    """(memory_idx, use_memory, n_slots) of one time step of a rank's sequence block: hand-sample i of the step (row
+    order of the crop plan: sequence-major, hands inside) keeps slot i on this rank at every step, and uses its memory
+    from the second step on (`use_memory=False` only at step 0, run_inference_torch_data.py:39-85)."""
+    s = int(hand_idx.shape[0])
+    return (torch.arange(s, dtype=torch.long, device=hand_idx.device),
+            torch.full((s,), 0 if first_step else 1, dtype=torch.uint8, device=hand_idx.device), s)
 
 
 def gather_records(local: torch.Tensor, world: int, equal_counts: bool = False) -> torch.Tensor:

@@ -7,6 +7,7 @@ packing of kernel argument rows, dict bookkeeping.  The heavy steps run natively
   * fisheye->pinhole resampling of every crop          -> csrc/warp.hip  (ut_warp_crops)
   * the network                                        -> ut_backbone + ut_fuse_temporal_regress
 """
+import contextlib
 import logging
 from dataclasses import dataclass
 from typing import Dict, List, NamedTuple, Optional, Tuple
@@ -267,18 +268,15 @@ class HandTracker:
         self._frame_stage: Optional[_Stage] = None      # staging of track_frame
         self._frame_stage_key = None
         self._limits_dev = None                         # (joint_limits tensor identity, device copy)
-        self._latency_engine = None                     # the engine ut_set_latency_mode was applied to
 
     def reset_history(self) -> None:
         self._valid_tracking_history[:] = False
 
     def _engine(self):
-        """The model's native engine, in latency mode: the tracker feeds it one frame (<= 4 crops) at a time."""
-        eng = self._model.engine
-        if self._latency_engine is not eng:
-            eng.set_latency_mode(True)
-            self._latency_engine = eng
-        return eng
+        """The model's native engine.  The tracker feeds it one frame (<= 4 crops) at a time and switches it to latency
+        mode for the duration of each of its own calls (`eng.modes(...)`), so a batched user of the same handle keeps
+        the default dispatch."""
+        return self._model.engine
 
     def gen_crop_cameras(self, cameras: List[CameraModel], camera_angles: List[float], hand_model: HandModel,
                          gt_tracking: Dict[int, SingleHandPose], min_num_crops: int
@@ -447,7 +445,7 @@ class HandTracker:
                       ("k", np.float32, (nc, 3, 3)), ("ext", np.float32, (nc, 4, 4)), ("range", np.int64, (ns, 2)),
                       ("mem", np.int64, (ns,)), ("hand", np.int64, (ns,)), ("use", np.uint8, (ns,)),
                       ("skel", np.float32, (1, 2, 22, 3)), ("img", np.uint8, (4, hgt, wid))],
-                [("pose", np.float32, (ns, 60)), ("kp", np.float32, (ns, 21, 3))])
+                [("pose", np.float32, (ns, 60)), ("kp", np.float32, (ns, 21, 3)), ("status", np.int32, (2,))])
             self._frame_stage_key = key
             self._feat = torch.empty(nc, 72, 6, 6, device=dev)
             self._engine().reserve(nc, ns, NUM_HANDS)
@@ -490,8 +488,9 @@ class HandTracker:
         # (Replaying the sequence as a captured hipGraph was measured: no gain - the loop is bound by the ~0.9 ms of GPU
         # time, not by the ~65 launches - and one graph holding backbone + head hung on replay under ROCm 7.2 while
         # per-stage graphs replayed fine; the launches stay eager.)
-        eng.set_index_checks(deferred=True)      # every index tensor above was built here: nothing to wait for
-        try:
+        # deferred checks: every index tensor above was built here, nothing to wait for in mid-sequence; the verdict
+        # rides in the one read-back below (a set bit means the device skipped the head: the poses would be stale)
+        with eng.modes(deferred_checks=True, latency=True):
             feat = eng.warp_backbone(ti["img"][:n_used], ti["cam"][:n_used], ti["crop"][:n], ti["src_index"][:n],
                                      self._remap_mode, out=self._feat[:n])
             pose, _ = eng.fuse_temporal_regress(feat, ti["k"][:n], ti["ext"][:n], ti["range"][:s], ti["mem"][:s],
@@ -500,10 +499,11 @@ class HandTracker:
             if blob is not None:
                 eng.fk(blob, pose, pose[:, 22:], mirror=ti["hand"][:s], t_scale=M_TO_MM, ja_stride=60, xf_stride=60,
                        n=s, out=to["kp"][:s])
-        finally:
-            eng.set_index_checks(deferred=False)
+            eng.status_snapshot(to["status"])
         st.download()                                                         # one read-back
         o = st.np_out
+        if o["status"][0] != 0:
+            eng.poll_status()                                                 # raises for the failed check, clears it
         hand_poses, num_views, predicted_scales = {}, {}, {}
         for i, hand_idx in enumerate(hands):
             rec = o["pose"][i]
@@ -531,10 +531,12 @@ class HandTracker:
             if res is not None:
                 return res
         frame_data, frame_desc, skeleton_data = self._make_inputs(sample, hand_model, crop_cameras)
-        if calibrate:
-            out = self._model.regress_pose_pred_skel_scale(frame_data, frame_desc)
-        else:
-            out = self._model.regress_pose_use_skeleton(frame_data, frame_desc, skeleton_data)
+        scope = self._engine().modes(latency=True) if self._device == "cuda" else contextlib.nullcontext()
+        with scope:        # a frame's few crops: latency dispatch for this call only
+            if calibrate:
+                out = self._model.regress_pose_pred_skel_scale(frame_data, frame_desc)
+            else:
+                out = self._model.regress_pose_use_skeleton(frame_data, frame_desc, skeleton_data)
         return self._gen_tracking_result(out, frame_desc.hand_idx.cpu().numpy(), crop_cameras)
 
     def track_frame(self, sample: InputFrame, hand_model: HandModel, crop_cameras) -> TrackingResult:

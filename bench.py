@@ -239,8 +239,9 @@ def main():
         # the GPU box gives one GPU a 16-CPU share although os.cpu_count() reports the whole host
         threads = min(os.cpu_count() or 1, 16)
         r = checks.time_oracle(sd, args.cpu_frames, threads)
-        # the batched path against the oracle's outputs for the frames it has just computed, in both arithmetics
-        batched = [checks.batched_parity(sd, r, str(device), m) for m in (("fp32", "split_f16") if known else ())]
+        # the batched path, raw images -> keypoints, against the oracle for the frames it has just computed, in both
+        # arithmetics: with identical crop cameras, with each side's own cameras (cv2 remap), and in float-remap mode
+        batched = checks.batched_parity(sd, r, str(device)) if known else None
         cpu = {"value": round(r["hand_frames"] / r["seconds"], 2), "unit": "hand-frames/s", "cores": threads,
                "kind": "port",
                "sample": f"{args.cpu_frames} label frames ({r['hand_frames']} hand-frames) of the same workload, "
@@ -256,6 +257,13 @@ def main():
         if not known:
             parity.update({k: r[k] for k in ("scale_mean_build", "scale_mean_oracle", "scale_mean_abs_diff")})
 
+    # what the process group saw: backend, world size and every rank's device (so that an N>1 record shows N ranks on N GPUs)
+    me = {"rank": rank, "device": torch.cuda.get_device_name(device), "index": dev_index}
+    ranks = [me]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+
     if rank == 0:
         line = {
             "metric": "hand-frames/sec", "value": round(value, 1), "unit": "hand-frames/s", "n_gpus": world,
@@ -270,6 +278,9 @@ def main():
                        "frames_per_gpu": f_local, "hand_frames_per_step": s_local * world,
                        "crops_per_step": n_local * world, "src_image": "480x636 u8 x 4 cameras",
                        "parallelism": f"frame-shard x{world}" + ("" if args.backend == "nccl" else " (gloo rehearsal)"),
+                       "world": world, "backend": (dist.get_backend() if world > 1 else "none (single process)"),
+                       "collective": "one all_gather_into_tensor of the [S_local,123] records per step" if world > 1 else None,
+                       "ranks": ranks,
                        "outputs_finite": finite},
             "conv_arithmetic": args.conv, "split_f16_check": split_check, "exact_fp32_mode": fp32_mode,
             "parity_batched_vs_oracle": batched,

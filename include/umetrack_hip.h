@@ -74,6 +74,10 @@ int ut_set_index_checks(ut_handle h, int mode);
 /* Synchronises `stream`, returns UT_E_INVALID (and clears the flag) if an index check has failed in any
  * call on this handle since the last poll, else UT_OK. */
 int ut_poll_status(ut_handle h, void* stream);
+/* Stream-ordered device-to-device copy of the two status words (dst: int32 [2] on the device; [0] != 0: a check has failed
+ * since the last poll and the work that depended on it was skipped) - lets a UT_CHECK_DEFERRED caller that reads its
+ * results back in one transfer see the verdict in that transfer and call ut_poll_status only when there is one. */
+int ut_status_snapshot(ut_handle h, int32_t* dst, void* stream);
 
 /* 1 (default) or 2: with 2, a ut_backbone / ut_warp_backbone call of >= 1024 crops that fits one workspace pass runs as
  * two half-batches on two internal streams (joined to the caller's stream before the call's work is visible to it), so
@@ -133,6 +137,13 @@ int ut_set_backbone_chunk(ut_handle h, int crops_per_pass);
 int ut_warp_crops(ut_handle h, const uint8_t* src, int n_src_images, int src_h, int src_w,
                   const double* cam_params, const double* crop_params, const int32_t* src_index,
                   int n_crops, int remap_mode, float* out, void* stream);
+
+/* Diagnostic / test entry: the fp32 coordinate map ut_warp_crops samples with, i.e. the array the reference hands to
+ * cv2.remap (lib/tracker/tracker.py:69-85: fp64 camera arithmetic cast to float32).  out_map f32 [n_crops,96,96,2] (x, y);
+ * cam_params / crop_params / src_index as for ut_warp_crops; a src_index outside [0, n_src_images) gives (-1, -1).
+ * Stateless, runs on the current device. */
+int ut_warp_map(const double* cam_params, const double* crop_params, const int32_t* src_index, int n_src_images,
+                int n_crops, float* out_map, void* stream);
 
 /* FeatureExtractor._image_backbone: lib/models/model_utils.py:107-138,
  * lib/models/backbone_resnet.py:14-192, called at lib/models/umetrack_model.py:127-129.

@@ -306,6 +306,19 @@ def export_idxbin():
             else:
                 assert got == frames[i], (name, i)
     assert ridx.TorchIdx(os.path.join(GOLD, "seq_mono.torch.idx")).shape == (3, 2, 2, 16, 24)
+    # byte_offset / byte_offsets of the reference's TorchIdx on the three fixtures (uniform and ragged branch),
+    # incl. the end == -1 and end == N + 1 forms its async reader uses (lib/data_utils/idxbinfile.py:196-231)
+    offs = {}
+    for name in ("seq_mono", "seq_labels", "ragged_f32"):
+        ref = ridx.TorchIdx(os.path.join(GOLD, name + ".torch.idx"))
+        n = len(ref)
+        offs[name + ".n"] = np.int64(n)
+        offs[name + ".to_minus1"] = np.asarray(ref.byte_offsets(0, -1)).astype(np.int64)
+        offs[name + ".to_n_plus_1"] = np.asarray(ref.byte_offsets(0, n + 1)).astype(np.int64)
+        offs[name + ".from1_minus1"] = np.asarray(ref.byte_offsets(1, -1)).astype(np.int64)
+        offs[name + ".from1_to_n"] = np.asarray(ref.byte_offsets(1, n)).astype(np.int64)
+        offs[name + ".single"] = np.asarray([ref.byte_offset(i) for i in list(range(n + 1)) + [-1]], np.int64)
+    np.savez_compressed(os.path.join(GOLD, "idxbin_offsets.npz"), **offs)
 
 
 def main():

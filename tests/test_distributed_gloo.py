@@ -78,3 +78,59 @@ def test_gather_records_single_rank_is_identity():
     from absolutetrack_amd import pipeline
     x = torch.randn(5, pipeline.RECORD)
     assert pipeline.gather_records(x, 1) is x
+
+
+def _seq_worker(rank, world, port, n_seq, n_steps, q):
+    """Stand-in for sequence mode: the temporal state is a per-slot recurrence state[slot] = 0.5 * state[slot] + x(seq, hand, t)
+    kept rank-locally and indexed by the descriptors of pipeline.sequence_step_descriptors; a record is the state after
+    the step.  What is checked is that sharding by sequence + gathering per step reproduces the single-process run."""
+    sys.path.insert(0, ROOT)
+    from absolutetrack_amd import pipeline
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = pipeline.shard_sequences(n_seq, rank, world)
+    seq = torch.arange(lo, hi).repeat_interleave(2)                       # two hands per sequence, sequence-major
+    hand = torch.tensor([0, 1] * (hi - lo), dtype=torch.long)
+    state = torch.zeros(0)
+    out = []
+    for t in range(n_steps):
+        mem_idx, use, n_slots = pipeline.sequence_step_descriptors(hand, first_step=t == 0)
+        if state.shape[0] < n_slots:
+            state = torch.cat([state, torch.zeros(n_slots - state.shape[0])])
+        x = (seq * 2 + hand).float() * 0.25 + t                            # the step's input of (sequence, hand)
+        prev = torch.where(use.bool(), state[mem_idx], torch.zeros(len(mem_idx)))
+        state[mem_idx] = 0.5 * prev + x
+        rec = state[mem_idx][:, None] + torch.arange(pipeline.RECORD, dtype=torch.float32)[None] / 1000.0
+        out.append(pipeline.gather_records(rec, world)[:, 0].clone())
+    q.put((rank, torch.stack(out).tolist()))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_sequence_sharding_matches_single_process():
+    """pipeline.shard_sequences: whole hand-sequences per rank (temporal slots rank-local), per-step all-gather in
+    sequence order; 5 sequences x 2 hands x 4 steps at world 2 and 3 (unequal blocks) against world 1."""
+    ctx = mp.get_context("spawn")
+    n_seq, n_steps = 5, 4
+
+    def run(world):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_seq_worker, args=(r, world, port, n_seq, n_steps, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=180) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        return res
+
+    want = run(1)[0][1]
+    assert len(want) == n_steps and len(want[0]) == 2 * n_seq
+    assert want[1] != want[0]                                              # the state is engaged
+    for world in (2, 3):
+        for _rank, got in run(world):
+            assert got == want, world

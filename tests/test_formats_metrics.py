@@ -36,6 +36,22 @@ def test_idxbin_fixtures_parse_to_the_scenario(golden_dir):
     assert np.array_equal(seq["mono"], c["mono"][1]) and seq["labels"] == c["labels"][1]
 
 
+def test_idxbin_byte_offsets_match_reference(golden_dir):
+    """byte_offset / byte_offsets against the reference's own TorchIdx on the three fixtures (tests/golden/idxbin_offsets.npz,
+    written by oracle/gen_goldens.py from lib/data_utils/idxbinfile.py:196-231): `end == -1` stops before the end-of-data
+    offset on the uniform and on the ragged branch, `end == N + 1` includes it."""
+    g = np.load(os.path.join(golden_dir, "idxbin_offsets.npz"))
+    for name in ("seq_mono", "seq_labels", "ragged_f32"):
+        idx = formats.TorchIdx(os.path.join(golden_dir, name + ".torch.idx"))
+        n = int(g[name + ".n"])
+        assert len(idx) == n
+        assert np.array_equal(np.asarray(idx.byte_offsets(0, -1), np.int64), g[name + ".to_minus1"])
+        assert np.array_equal(np.asarray(idx.byte_offsets(0, n + 1), np.int64), g[name + ".to_n_plus_1"])
+        assert np.array_equal(np.asarray(idx.byte_offsets(1, -1), np.int64), g[name + ".from1_minus1"])
+        assert np.array_equal(np.asarray(idx.byte_offsets(1, n), np.int64), g[name + ".from1_to_n"])
+        assert [idx.byte_offset(i) for i in list(range(n + 1)) + [-1]] == g[name + ".single"].tolist()
+
+
 def test_idxbin_round_trip_and_errors(tmp_path):
     rng = np.random.default_rng(0)
     for dt in ("uint8", "int8", "int16", "int32", "int64", "float32", "float64"):

@@ -234,6 +234,21 @@ def test_shard_frames_partitions_exactly():
         assert max(sizes) - min(sizes) <= 1
 
 
+def test_shard_sequences_keeps_slots_rank_local():
+    """Sequence mode: a rank owns the same contiguous sequence block at every time step, a hand-sample keeps one local
+    slot, memory is used from the second step on (SURVEY.md section 8 e; lib/models/temporal.py:101-137)."""
+    import torch
+    for total, world in ((2048, 8), (10, 3), (5, 2)):
+        spans = [pipeline.shard_sequences(total, r, world) for r in range(world)]
+        assert spans == [pipeline.shard_frames(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+    hand = torch.tensor([0, 1, 0, 1, 0, 1])
+    m0, u0, n0 = pipeline.sequence_step_descriptors(hand, first_step=True)
+    m1, u1, n1 = pipeline.sequence_step_descriptors(hand, first_step=False)
+    assert m0.tolist() == list(range(6)) and torch.equal(m0, m1) and n0 == n1 == 6
+    assert u0.tolist() == [0] * 6 and u1.tolist() == [1] * 6 and u0.dtype == torch.uint8
+
+
 def test_synthetic_inputs_are_reproducible():
     a, b = synth.synthetic_crops(3, seed=4), synth.synthetic_crops(3, seed=4)
     assert np.array_equal(a, b) and a.dtype == np.float32 and 0 <= a.min() and a.max() <= 1

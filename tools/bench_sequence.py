@@ -28,7 +28,8 @@ def main():
     for t in range(seq):
         plan = {k: v.cpu().numpy() for k, v in pipeline.crop_plan_on_device(lab, hm, [i + t for i in range(f)], dev).items()}
         b = pipeline.make_batch(plan, src, dev)
-        b.use_memory = torch.full((b.n_samples,), 1 if t > 0 else 0, dtype=torch.uint8, device=dev)
+        # this process owns the whole sequence block (pipeline.shard_sequences(f, 0, 1)): slots stay local, memory from step 1
+        b.memory_idx, b.use_memory, b.n_slots = pipeline.sequence_step_descriptors(b.hand_idx, first_step=t == 0)
         batches.append(b)
     s = batches[0].n_samples
     assert all(b.n_samples == s for b in batches)
