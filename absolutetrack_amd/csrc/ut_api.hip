@@ -22,6 +22,8 @@ struct ConvW {
   float* w = nullptr;     // device [cout_pad][k_pad]
   void* w_split = nullptr;   // device: the two fp16 planes of w * 2^k in fragment order (conv_split.hip), eligible layers only
   float split_unscale = 0.f; // 2^-k
+  float wsum_rows = 0.f;     // max over output channels of sum_k |w| (folded), rounded up: bounds |conv(x)| by wsum_rows * max|x|
+  float bias_max = 0.f;      // max |bias| (folded)
   float* bias = nullptr;  // device [cout_pad]
   int cin = 0, cin_pad = 0, cout = 0, cout_pad = 0, cout_store = 0;
   int taps = 1, ksize = 1, stride = 1, pad = 0, k_total = 0, k_pad = 0, cslice = 0;
@@ -85,6 +87,7 @@ struct ut_context {
   unsigned* counters = nullptr;
   int counter_next = 0;
   unsigned word_gen = 0;            // bumped by every zeroing of the words: a max word kept across launches is stale after it
+  bool block_fusion = true;         // split-fp16 mode: layer1's BasicBlocks as one launch each (ut_set_block_fusion)
   bool call_split = false;          // the running backbone call uses the split-fp16 kernels (decided once per call)
   // index checks: device status words ([0] sticky errors, [1] per call), their pinned host mirror, the duplicate-slot
   // scratch (slots_cap ints, allocated with the temporal state) and the mode (UT_CHECK_*)
@@ -254,6 +257,17 @@ int pack_conv(ut_handle h, ConvW& cw, const float* w, const float* conv_bias, co
       for (int t = 0; t < cw.taps; ++t)
         wp[(size_t)o * cw.k_pad + (c / cw.cslice) * (cw.taps * cw.cslice) + t * cw.cslice + c % cw.cslice] =
             (float)((double)w[((size_t)o * cin + c) * cw.taps + t] * s);
+  }
+  {
+    double ws = 0.0, bm = 0.0;
+    for (int o = 0; o < cout; ++o) {
+      double rs = 0.0;
+      for (int k = 0; k < cw.k_pad; ++k) rs += fabs((double)wp[(size_t)o * cw.k_pad + k]);
+      ws = rs > ws ? rs : ws;
+      bm = fabs((double)bp[o]) > bm ? fabs((double)bp[o]) : bm;
+    }
+    cw.wsum_rows = (float)(ws * 1.0001);
+    cw.bias_max = (float)(bm * 1.0001);
   }
   int rc = upload(h, wp, &cw.w);
   if (rc) return rc;
@@ -496,6 +510,43 @@ int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, fl
 int run_block(ut_handle h, const Block& b, const float* x, float* tmp, float* dsbuf, float* y, int n_img, int H,
               int W, hipStream_t s, const unsigned* x_max = nullptr, unsigned** y_max = nullptr) {
   int rc;
+  if (y_max) *y_max = nullptr;
+  // layer1 in split-fp16 mode: the whole block in one launch, the intermediate stays in LDS (conv_block32.hip)
+  if (h->call_split && h->block_fusion && x_max && !h->latency_mode && !b.has_ds && b.conv1.w_split && b.conv2.w_split && b.conv1.stride == 1 &&
+      b.conv1.cin_pad == 32 && b.conv1.cout_store == 32 && b.conv2.cout_store == 32) {
+    ut::BlockLaunch bl{};
+    bl.in = x; bl.out = y; bl.w1_split = b.conv1.w_split; bl.w2_split = b.conv2.w_split;
+    bl.unscale_w1 = b.conv1.split_unscale; bl.unscale_w2 = b.conv2.split_unscale;
+    bl.bias1 = b.conv1.bias; bl.bias2 = b.conv2.bias;
+    bl.wsum1 = b.conv1.wsum_rows; bl.bmax1 = b.conv1.bias_max;
+    bl.in_max = x_max; bl.status = h->status;
+    bl.n_img = n_img; bl.H = H; bl.W = W; bl.device = h->device; bl.num_cu = h->num_cu;
+    if (ut::conv_block32_applicable((bl.tile_counter = h->counters, bl))) {
+      const unsigned gen = h->word_gen;
+      int word = 0;
+      if ((rc = next_launch_word(h, s, &word))) return rc;
+      if (gen == h->word_gen) {          // (a recycle in mid-call zeroed x's word: fall through to the two-launch path)
+        bl.tile_counter = h->counters + word;
+        bl.out_max = h->counters + kMaxCounters + word;
+        ProfEvent pe{};
+        if (h->profiling) {
+          HIPCHK(h, hipEventCreateWithFlags(&pe.a, hipEventDisableSystemFence));
+          HIPCHK(h, hipEventCreateWithFlags(&pe.b, hipEventDisableSystemFence));
+          pe.flops = (b.conv1.flops_per_pixel + b.conv2.flops_per_pixel) * (double)n_img * H * W;
+          pe.kind = 1;
+          HIPCHK(h, hipEventRecord(pe.a, s));
+        }
+        HIPCHK(h, ut::launch_conv_block32(bl, s));
+        if (h->profiling) {
+          HIPCHK(h, hipEventRecord(pe.b, s));
+          h->prof.push_back(pe);
+        }
+        if (y_max) *y_max = bl.out_max;
+        return UT_OK;
+      }
+      x_max = nullptr;
+    }
+  }
   unsigned* tmp_max = nullptr;
   if ((rc = run_conv(h, b.conv1, x, nullptr, tmp, n_img, H, W, true, false, s, x_max, &tmp_max))) return rc;
   const int Ho = (H + 2 - 3) / b.conv1.stride + 1, Wo = (W + 2 - 3) / b.conv1.stride + 1;
@@ -1036,6 +1087,12 @@ int ut_set_backbone_lanes(ut_handle h, int lanes) {
 int ut_set_conv_arithmetic(ut_handle h, int mode) {
   if (!h || (mode != UT_CONV_FP32 && mode != UT_CONV_SPLIT_F16 && mode != UT_CONV_SPLIT_F16_ALWAYS)) return fail(h, UT_E_INVALID, "ut_set_conv_arithmetic: bad argument");
   h->conv_arith = mode;
+  return UT_OK;
+}
+
+int ut_set_block_fusion(ut_handle h, int on) {
+  if (!h) return UT_E_INVALID;
+  h->block_fusion = on != 0;
   return UT_OK;
 }
 

@@ -49,6 +49,27 @@ bool conv_split_applicable(const ConvLaunch& c);
 hipError_t launch_conv_split(const ConvLaunch& c, hipStream_t s);
 size_t pack_split_weights(const float* w, int cout_pad, int k_pad, float scale, uint16_t* out);
 float split_weight_scale(const float* w, size_t n);
+// One 32 -> 32 -> 32 channel BasicBlock (stride 1, no shortcut convolution) in one launch, split-fp16 arithmetic
+// (conv_block32.hip): out = relu(conv2(relu(conv1(in) + bias1)) + bias2 + in), BatchNorm folded into weights and biases.
+struct BlockLaunch {
+  const float* in;          // [n_img, H, W, 32]
+  float* out;               // [n_img, H, W, 32]
+  const void* w1_split;     // ConvW::w_split of the two convolutions (fp16 planes in fragment order, pre-scaled)
+  const void* w2_split;
+  float unscale_w1, unscale_w2;   // 1 / weight scale
+  const float* bias1;
+  const float* bias2;
+  float wsum1;              // max over output channels of sum_k |w1| (folded): bounds the intermediate with max|in| and bmax1
+  float bmax1;              // max |bias1|
+  const unsigned* in_max;   // max word of `in` (never null)
+  unsigned* out_max;        // optional: receives the bits of max |out|
+  int* status;
+  unsigned* tile_counter;
+  int n_img, H, W, device, num_cu;
+};
+bool conv_block32_applicable(const BlockLaunch& b);
+hipError_t launch_conv_block32(const BlockLaunch& b, hipStream_t s);
+
 // *dst = max(*dst, *src) on two max words (one thread): the activation of several passes read by one consumer
 hipError_t launch_merge_max(unsigned* dst, const unsigned* src, hipStream_t s);
 // 3x3 stride-1 32->32 channel convs with the halo patch resident in LDS (conv_patch.hip)

@@ -109,6 +109,12 @@ int ut_set_backbone_lanes(ut_handle h, int lanes);
 enum { UT_CONV_FP32 = 0, UT_CONV_SPLIT_F16 = 1, UT_CONV_SPLIT_F16_ALWAYS = 2 };
 int ut_set_conv_arithmetic(ut_handle h, int mode);
 
+/* Split-fp16 mode only: run each BasicBlock of layer1 (32 -> 32 -> 32 channels at 48x48) as ONE launch whose intermediate
+ * relu(bn1(conv1 x)) stays in LDS (csrc/conv_block32.hip) instead of two convolution launches with a round trip through HBM
+ * (1 = default).  Same arithmetic; the intermediate's power-of-two scale comes from a bound instead of the measured maximum,
+ * so the two forms agree to the split arithmetic's rounding (~1e-7 relative), not bit for bit.  0 is for A/B tests. */
+int ut_set_block_fusion(ut_handle h, int on);
+
 /* Latency mode for calls on a handful of crops (the per-frame tracker): convolutions whose launch has far fewer tiles
  * than the chip has CUs split K across workgroups and add the partial sums in a fixed order.  Deterministic, but not
  * the unsplit kernel's summation order: results agree with the default mode to fp32 rounding (~1e-6 relative), not

@@ -105,6 +105,28 @@ def test_split_f16_backbone_matches_oracle(engine, split_engine):
     assert torch.equal(split_engine.backbone(_dev(crops)).cpu(), got)       # deterministic
 
 
+def test_split_f16_fused_layer1_blocks_match_the_two_launch_form(engine, split_engine):
+    """conv_block32.hip (layer1's BasicBlocks as one launch each, the intermediate in LDS) against the same arithmetic as two
+    convolution launches per block: the forms differ only in the intermediate's power-of-two scale (a bound there, the
+    measured maximum here), i.e. in how the smallest values round - far inside the split arithmetic's own distance to fp32.
+    37 crops = 444 tiles on 256 persistent workgroups (the tile queue and the double-buffered patch are exercised)."""
+    crops = _dev(synth.synthetic_crops(37, seed=11))
+    fused = split_engine.backbone(crops)
+    split_engine.set_block_fusion(False)
+    try:
+        two = split_engine.backbone(crops)
+    finally:
+        split_engine.set_block_fusion(True)
+    assert torch.equal(split_engine.backbone(crops), fused)          # deterministic
+    fp32 = engine.backbone(crops)
+    scale = max(1.0, fp32.abs().max().item())
+    assert (fused - two).abs().max().item() < 2e-6 * scale
+    assert (fused - fp32).abs().max().item() < 1e-5 * scale
+    assert (two - fp32).abs().max().item() < 1e-5 * scale
+    want = ref_model.backbone(ref_model.to_torch_state_dict(synth.synthetic_state_dict(0)), crops[:6].cpu())
+    assert (fused[:6].cpu() - want).abs().max().item() < 2e-5 * scale
+
+
 def _rescaled_state_dict(k: int):
     """synthetic_state_dict(0) with every backbone block's bn1.{weight,bias} x 2^-k and conv2.weight x 2^k: the activations
     between conv1 and conv2 of every block are 2^-k of the original network's, everything else - in exact arithmetic and
