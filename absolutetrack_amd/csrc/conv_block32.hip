@@ -4,8 +4,9 @@
 // by its tile's HBM traffic - patch in, residual in, tile out: 3.8 TB/s at 1 ms per launch - and the intermediate
 // relu(bn1(conv1 x)) makes a full round trip through HBM.  Here a workgroup owns a 12x16-pixel OUTPUT tile:
 //   * the 16x20x32 input patch (tile + a halo of 2) comes into LDS once by LDS-DMA, double buffered across tiles;
-//   * the residual (the fp32 centre of that patch) is read into registers, then the patch is split IN PLACE into the two
-//     fp16 pieces per value (a value's pieces take its 4 bytes; scaled by the power of two of ut_kernels.h::split_act_scale);
+//   * the patch is split IN PLACE into the two fp16 pieces per value (a value's pieces take its 4 bytes; scaled by the power
+//     of two of ut_kernels.h::split_act_scale) - by waves 6 and 7, which have no conv2 block, while waves 0..5 run conv2 of
+//     the tile before; the residual (the fp32 centre pixels) is read into registers by waves 0..5 just before that;
 //   * conv1 runs on the 14x18 intermediate pixels (tile + halo of 1: 252 pixels = 8 MFMA blocks of 32, one per wave),
 //     BatchNorm + ReLU applied, intermediate pixels outside the image set to zero (they are conv2's zero padding);
 //   * the intermediate never leaves the CU: once every wave is done reading the patch it is split and written over the patch;
@@ -74,6 +75,14 @@ __device__ __forceinline__ u32x4b b_rsrc(const void* base, unsigned bytes) {
 __device__ __forceinline__ void b_split(float a, float b, unsigned& p0, unsigned& p1) {
   const f16x2b h = __builtin_bit_cast(f16x2b, __builtin_amdgcn_cvt_pkrtz(a, b));
   const float ra = a - (float)h[0], rb = b - (float)h[1];
+  p0 = __builtin_bit_cast(unsigned, h);
+  p1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+}
+// the two pieces of a * s and b * s for a power of two s: the products are exact, so fma(a, s, -h) is the same remainder as
+// (a * s) - h, in one instruction that also converts h (v_fma_mix_f32)
+__device__ __forceinline__ void b_split_scaled(float a, float b, float s, unsigned& p0, unsigned& p1) {
+  const f16x2b h = __builtin_bit_cast(f16x2b, __builtin_amdgcn_cvt_pkrtz(a * s, b * s));
+  const float ra = __builtin_fmaf(a, s, -(float)h[0]), rb = __builtin_fmaf(b, s, -(float)h[1]);
   p0 = __builtin_bit_cast(unsigned, h);
   p1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
 }
@@ -180,7 +189,6 @@ __global__ __launch_bounds__(64 * B_WAVES) void conv_block32_kernel(BlockLaunch 
   const int oy = q2 >> 4, ox = q2 & 15;
   static_assert(BT_X == 16, "q2 >> 4");
   const int p2base = oy * BI_W + ox;                   // intermediate row of tap (0, 0)
-  const int res_row = (oy + 2) * BP_W + ox + 2;        // patch row of my output pixel (the residual)
 
   float4 b1r[4], b2r[4];
 #pragma unroll
@@ -211,6 +219,43 @@ __global__ __launch_bounds__(64 * B_WAVES) void conv_block32_kernel(BlockLaunch 
   const char* w1_bytes = smem + W1_OFF + lane * 16;
   const char* w2_bytes = smem + W2_OFF + lane * 16;
 
+  // split one patch row in place (group q = 4 * piece + k / 8 at position q ^ swizzle)
+  auto convert_row = [&](char* reg, int row) {
+    const int sw = (row >> 1) & 7;
+    char* rp = reg + row * 128;
+    float4 f[8];
+#pragma unroll
+    for (int g4 = 0; g4 < 8; ++g4) f[g4] = *reinterpret_cast<const float4*>(rp + ((g4 ^ sw) << 4));
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      unsigned a0, a1, a2, a3, b0, b1, b2, b3;
+      b_split_scaled(f[2 * kg].x, f[2 * kg].y, x_scale, a0, b0);
+      b_split_scaled(f[2 * kg].z, f[2 * kg].w, x_scale, a1, b1);
+      b_split_scaled(f[2 * kg + 1].x, f[2 * kg + 1].y, x_scale, a2, b2);
+      b_split_scaled(f[2 * kg + 1].z, f[2 * kg + 1].w, x_scale, a3, b3);
+      u32x4b a, b;
+      a.x = a0; a.y = a1; a.z = a2; a.w = a3;
+      b.x = b0; b.y = b1; b.z = b2; b.w = b3;
+      *reinterpret_cast<u32x4b*>(rp + ((kg ^ sw) << 4)) = a;
+      *reinterpret_cast<u32x4b*>(rp + (((4 + kg) ^ sw) << 4)) = b;
+    }
+  };
+  // the residual of my output pixel (waves 0..5): the fp32 centre of a landed patch, read before the patch is split
+  const int res_row = (oy + 2) * BP_W + ox + 2;
+  u32x4b rr[4];
+  auto read_residual = [&](const char* reg) {
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+      rr[g4] = *reinterpret_cast<const u32x4b*>(reg + res_row * 128 + (((2 * g4 + fh) ^ ((res_row >> 1) & 7)) << 4));
+  };
+  // the first tile's patch: residual, then everybody converts
+  if (has_u2) read_residual(smem + R_OFF);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();
+  if (tid < BP_PIX) convert_row(smem + R_OFF, tid);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();
+
 #define B_PIN() __builtin_amdgcn_sched_barrier(0)
 #define B_READ(SET, REGION, WB, PBASE, ROWW, TAP, S)                                                 \
   {                                                                                                  \
@@ -231,44 +276,8 @@ __global__ __launch_bounds__(64 * B_WAVES) void conv_block32_kernel(BlockLaunch 
   for (;;) {
     const bool has_next = next < n_tiles;
     char* region = smem + R_OFF + cur * B_R_BYTES;
-    // ---- A: the residual of my output pixel, fp32, before the patch is split in place
-    u32x4b rr[4];
-    if (has_u2) {
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4)
-        rr[g4] = *reinterpret_cast<const u32x4b*>(region + res_row * 128 + (((2 * g4 + fh) ^ ((res_row >> 1) & 7)) << 4));
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
-    __builtin_amdgcn_s_barrier();            // S1: every residual is in registers
-    // ---- B: split the patch in place, one row per thread (group q = 4 * piece + k / 8 at position q ^ swizzle)
-    if (tid < BP_PIX) {
-      const int sw = (tid >> 1) & 7;
-      char* rp = region + tid * 128;
-      float4 f[8];
-#pragma unroll
-      for (int g4 = 0; g4 < 8; ++g4) {
-        f[g4] = *reinterpret_cast<const float4*>(rp + ((g4 ^ sw) << 4));
-        f[g4].x *= x_scale; f[g4].y *= x_scale; f[g4].z *= x_scale; f[g4].w *= x_scale;
-      }
-#pragma unroll
-      for (int kg = 0; kg < 4; ++kg) {
-        unsigned a0, a1, a2, a3, b0, b1, b2, b3;
-        b_split(f[2 * kg].x, f[2 * kg].y, a0, b0);
-        b_split(f[2 * kg].z, f[2 * kg].w, a1, b1);
-        b_split(f[2 * kg + 1].x, f[2 * kg + 1].y, a2, b2);
-        b_split(f[2 * kg + 1].z, f[2 * kg + 1].w, a3, b3);
-        u32x4b a, b;
-        a.x = a0; a.y = a1; a.z = a2; a.w = a3;
-        b.x = b0; b.y = b1; b.z = b2; b.w = b3;
-        *reinterpret_cast<u32x4b*>(rp + ((kg ^ sw) << 4)) = a;
-        *reinterpret_cast<u32x4b*>(rp + (((4 + kg) ^ sw) << 4)) = b;
-      }
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_s_barrier();            // S2: the split patch is complete
-
     // ---- C: conv1 on my 32 intermediate pixels.  The next tile's patch pieces and the queue ticket are requested between
-    // the MFMA groups of the first taps (the other region is free: its last readers, conv2 of the previous tile, passed S1).
+    // the MFMA groups of the first taps (the other region is free: its last readers, conv2 of the previous tile, passed S2).
     const int ticket = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, q_rsrc, q_off, 0, 0);
     int n_row0 = 0, n_y0 = 0, n_x0 = 0;
     if (has_next) tile_origin(next, n_row0, n_y0, n_x0);
@@ -325,7 +334,8 @@ __global__ __launch_bounds__(64 * B_WAVES) void conv_block32_kernel(BlockLaunch 
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();            // S4: the intermediate is complete, the next patch has landed
 
-    // ---- D: conv2 on my 32 output pixels (waves 0..5), bias + residual, ReLU, store
+    // ---- D: conv2 on my 32 output pixels (waves 0..5), bias + residual, ReLU, store.  The accumulators take this tile's
+    // residual; the registers then take the next tile's, from its landed fp32 patch, before waves 6 and 7 split it (S5).
     if (has_u2) {
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
@@ -334,6 +344,12 @@ __global__ __launch_bounds__(64 * B_WAVES) void conv_block32_kernel(BlockLaunch 
         acc[4 * g4 + 2] = (b2r[g4].z + __uint_as_float(rr[g4].z)) * acc2_scale;
         acc[4 * g4 + 3] = (b2r[g4].w + __uint_as_float(rr[g4].w)) * acc2_scale;
       }
+      asm volatile("" : "+v"(acc));
+      if (has_next) read_residual(smem + R_OFF + (cur ^ 1) * B_R_BYTES);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();            // S5: the next tile's residuals are in registers
+    if (has_u2) {
       u32x4b prX[2], prY[2], wqX[2], wqY[2];
       B_READ(X, region, w2_bytes, p2base, BI_W, 0, 0);
 #pragma unroll
@@ -353,8 +369,15 @@ __global__ __launch_bounds__(64 * B_WAVES) void conv_block32_kernel(BlockLaunch 
         out_bits = max(max(out_bits, max(pk.x & 0x7FFFFFFFu, pk.y & 0x7FFFFFFFu)), max(pk.z & 0x7FFFFFFFu, pk.w & 0x7FFFFFFFu));
         __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, (unsigned)(m * C + 8 * g4 + 4 * fh) * 4u, 0, 0);
       }
+    } else if (has_next) {
+      // ---- waves 6, 7 (no conv2 block): split the next tile's patch, landed before S4, in place
+      char* nreg = smem + R_OFF + (cur ^ 1) * B_R_BYTES;
+#pragma unroll 1
+      for (int row = tid - 64 * U2; row < BP_PIX; row += 64 * (B_WAVES - U2)) convert_row(nreg, row);
     }
     if (!has_next) break;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();            // S2: the next patch is split; conv2's reads of this region are done
     const int next2 = slot_read(cur);        // written before S4
     tile = next;
     next = next2;

@@ -35,11 +35,14 @@ VARIANTS = {
     # no counted vmcnt wait at the arrival (racy: timing only)
     "nowait": [("      if (skip_waits > 0) --skip_waits;  ", "      if (p.k_pad >= 0) {} else if (skip_waits > 0) --skip_waits;  ")],
 }
+VARIANTS["noearlywait"] = [("      if constexpr (EARLY_RES) asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");", "")]
 variants = [v for v in os.environ.get("SPLIT_VARIANTS", "").split(",") if v]
+# SPLIT_ALT_SRC=<path>: another conv_split.hip (e.g. an earlier commit's, `git show <rev>:absolutetrack_amd/csrc/conv_split.hip`) as variant "alt"
+ALT_SRC = os.environ.get("SPLIT_ALT_SRC")
 
 
-def build(name, patches, flags=()):
-    src = os.path.join(CSRC, "conv_split.hip")
+def build(name, patches, flags=(), alt=None):
+    src = alt or os.path.join(CSRC, "conv_split.hip")
     if patches:
         text = open(src).read()
         for old, new in patches:
@@ -64,6 +67,8 @@ for v in variants:
         else:
             patches += VARIANTS[part]
     vlibs[v] = build(v.replace("=", "_"), patches, flags)
+if ALT_SRC:
+    vlibs["alt"] = build("alt", [], alt=ALT_SRC)
 dev = "cuda:0"
 torch.manual_seed(0)
 ho = (hw + 2 * (ksize // 2) - ksize) // stride + 1

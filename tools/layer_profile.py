@@ -23,6 +23,7 @@ def block_convs(bi, hw):
     out.append((f"b{bi}.conv2 {co}->{co} @{ho}", 2 * 9 * co * co * ho * ho))
     return out, ho
 
+fused_l1 = any("conv_block32" in r["Kernel_Name"] for r in rows)   # split-fp16 mode: layer1's blocks are one launch each
 seq = []   # (name, flops for the launch)
 n_chunks = (n_crops + chunk - 1) // chunk
 for c in range(n_chunks):
@@ -30,6 +31,8 @@ for c in range(n_chunks):
     hw = 48
     for bi in range(5):
         cs, hw = block_convs(bi, hw)
+        if fused_l1 and bi < 2:
+            cs = [(f"b{bi}.block 32->32->32 @{hw}", sum(fl for _, fl in cs))]
         seq += [(nm, fl * n) for nm, fl in cs]
 hw = 24
 for bi in range(5, 12):
@@ -42,13 +45,15 @@ head = [("fus0 144->108", 144 * 108), ("fus1 108->72", 108 * 72), ("fus2 72->72"
         ("reg1.conv1 76", 9 * 76 * 76), ("reg1.conv2 76", 9 * 76 * 76)]
 seq += [(nm, 2 * mac * 36 * s) for nm, mac in head]
 
-is_conv = lambda r: any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_c32_patch", "conv_split"))
+is_conv = lambda r: any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_c32_patch", "conv_split", "conv_block32"))
 
 
 def label(name):
     args = name.split("<")[1].split(">")[0] if "<" in name else ""
     if "conv_split" in name:
         return "split f16 " + "x".join(args.split(", ")[:2])
+    if "conv_block32" in name:
+        return "fused block 12x16 split f16"
     if "conv3x3_c32_patch" in name:
         return "halo patch 16x24" + (" split f16" if args == "true" else "")
     return "fp32 " + "x".join(args.split(", ")[:2])
