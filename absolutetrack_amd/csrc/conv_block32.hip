@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64 * B_WAVES) void conv_block32_kernel(BlockLaunch 
   }
 
   for (;;) {
-    const bool has_next = next < n_tiles;
+    const bool has_next = (unsigned)next < (unsigned)n_tiles;     // (unsigned: a corrupt queue word cannot keep the loop alive)
     char* region = smem + R_OFF + cur * B_R_BYTES;
     // ---- C: conv1 on my 32 intermediate pixels.  The next tile's patch pieces and the queue ticket are requested between
     // the MFMA groups of the first taps (the other region is free: its last readers, conv2 of the previous tile, passed S2).

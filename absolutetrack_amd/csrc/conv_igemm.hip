@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvLaunch p, int ti
     UT_SETUP(next);
     UT_CHUNK_FINE_LAST(buf, next);
     buf ^= 1;
-    if (next >= n_tiles) break;
+    if ((unsigned)next >= (unsigned)n_tiles) break;     // (unsigned: a corrupt queue word cannot keep the loop alive)
     tile = next;
   }
 #undef UT_SLOT_WRITE

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
   f32x16 ready = init_combine();      // bias + residual of the tile about to be computed
   f32x16 acc;
   for (;;) {
-    const bool has_next = next < n_tiles;
+    const bool has_next = (unsigned)next < (unsigned)n_tiles;     // (unsigned: a corrupt queue word cannot keep the loop alive)
     if (late && have_prev) { UTP_EPILOGUE(prev_m); }
     acc = ready;
     // ticket for the tile after next: issued now, consumed before the last tap

@@ -630,7 +630,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
       }
       skip_waits = 2;
     }
-    if (next_tile >= n_tiles) break;
+    if ((unsigned)next_tile >= (unsigned)n_tiles) break;     // (unsigned: a corrupt queue word cannot keep the loop alive)
     tile = next_tile;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the transfers issued for tiles that do not exist

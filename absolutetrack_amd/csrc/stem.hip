@@ -108,6 +108,17 @@ hipError_t launch_stem_u8(const uint8_t* crops, const float* w, const float* bia
   return launch_stem_t(crops, w, bias, out, n, out_max, s);
 }
 
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned* p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+hipError_t launch_zero_words(void* p, size_t n_words, hipStream_t s) {
+  if (!n_words) return hipSuccess;
+  size_t blocks = (n_words + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (unsigned*)p, n_words);
+  return hipGetLastError();
+}
+
 __global__ void merge_max_kernel(unsigned* dst, const unsigned* src) { atomicMax(dst, *src); }
 
 hipError_t launch_merge_max(unsigned* dst, const unsigned* src, hipStream_t s) {

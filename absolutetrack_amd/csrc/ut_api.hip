@@ -419,7 +419,7 @@ constexpr int kMaxCounters = 4096;
 int begin_call(ut_handle h, hipStream_t s) {
   h->counter_next = 0;
   ++h->word_gen;
-  HIPCHK(h, hipMemsetAsync(h->counters, 0, 2 * kMaxCounters * sizeof(unsigned), s));
+  HIPCHK(h, ut::launch_zero_words(h->counters, 2 * kMaxCounters, s));      // a kernel, not a memset node: see launch_zero_words
   return UT_OK;
 }
 
@@ -940,8 +940,8 @@ int ut_fuse_temporal_regress(ut_handle h, const float* feat, const float* intrin
   a.status = h->status; a.slot_seen = h->slot_seen;
   a.call_error_mask = mode == UT_MODE_UNKNOWN_SKELETON ? ut::UT_SINGLE_VIEW : 0;
   // index checks (stream ordered, in front of everything that indexes with the descriptors)
-  HIPCHK(h, hipMemsetAsync(h->status + 1, 0, sizeof(int), s));
-  HIPCHK(h, hipMemsetAsync(h->slot_seen, 0, (size_t)n_slots * sizeof(int), s));
+  HIPCHK(h, ut::launch_zero_words(h->status + 1, 1, s));
+  HIPCHK(h, ut::launch_zero_words(h->slot_seen, (size_t)n_slots, s));
   HIPCHK(h, ut::launch_validate_desc(a, s));
   if (h->check_mode == UT_CHECK_SYNC) {
     int sticky = 0, call = 0;

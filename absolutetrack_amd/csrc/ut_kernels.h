@@ -70,6 +70,10 @@ struct BlockLaunch {
 bool conv_block32_applicable(const BlockLaunch& b);
 hipError_t launch_conv_block32(const BlockLaunch& b, hipStream_t s);
 
+// n 32-bit words := 0, as a kernel.  NOT hipMemsetAsync: captured into a hipGraph, a memset node of 16 bytes or more fills with
+// a stale pattern from the second replay on (ROCm 7.2; tools/diag/graph_memset.py) - a garbage tile-queue word then walks a
+// persistent kernel through ~10^9 tickets, which is what hung the whole-path graph replay of round 2.
+hipError_t launch_zero_words(void* p, size_t n_words, hipStream_t s);
 // *dst = max(*dst, *src) on two max words (one thread): the activation of several passes read by one consumer
 hipError_t launch_merge_max(unsigned* dst, const unsigned* src, hipStream_t s);
 // 3x3 stride-1 32->32 channel convs with the halo patch resident in LDS (conv_patch.hip)

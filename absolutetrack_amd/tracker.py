@@ -485,9 +485,9 @@ class HandTracker:
             blob = device_blob(hand_model, dev)
         n_used, n_slots = len(used), max(hands) + 1
 
-        # (Replaying the sequence as a captured hipGraph was measured: no gain - the loop is bound by the ~0.9 ms of GPU
-        # time, not by the ~65 launches - and one graph holding backbone + head hung on replay under ROCm 7.2 while
-        # per-stage graphs replayed fine; the launches stay eager.)
+        # (Replaying the sequence as a captured hipGraph was measured in round 2: no gain - the loop is bound by the ~0.9 ms of
+        # GPU time, not by the ~65 launches; the launches stay eager.  The whole-path replay hang of that experiment was the
+        # library's hipMemsetAsync nodes: see csrc/ut_kernels.h::launch_zero_words.)
         # deferred checks: every index tensor above was built here, nothing to wait for in mid-sequence; the verdict
         # rides in the one read-back below (a set bit means the device skipped the head: the poses would be stale)
         with eng.modes(deferred_checks=True, latency=True):

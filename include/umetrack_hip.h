@@ -24,6 +24,11 @@
  *    UT_E_INVALID; with ut_set_index_checks(h, UT_CHECK_DEFERRED) nothing synchronises (needed inside
  *    hipGraph capture and for run-ahead launching), the affected work is skipped on the device and
  *    the error is reported by the next ut_poll_status.
+ *  - stream capture: with UT_CHECK_DEFERRED and the workspace sized beforehand (ut_reserve, or one eager call of the same
+ *    shapes) the compute entries only enqueue kernels on the given stream - no allocation, no synchronisation, and no memset
+ *    nodes (the library zeroes its per-launch words with a kernel: captured hipMemsetAsync nodes replay a stale fill
+ *    pattern under ROCm 7.2) - so ut_warp_backbone + ut_fuse_temporal_regress + ut_fk can be captured into ONE hipGraph
+ *    and replayed (tests/test_gpu_tracker.py::test_whole_step_replays_from_one_hipgraph).
  */
 #ifndef UMETRACK_HIP_H
 #define UMETRACK_HIP_H

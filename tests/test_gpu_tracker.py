@@ -272,6 +272,49 @@ def test_tracker_and_hotpath_share_one_handle(labels, hand_model):
     hot.check()
 
 
+@pytest.mark.timeout(180, method="thread")
+@pytest.mark.parametrize("conv,frames", [("fp32", 24), ("split_f16", 300)])
+def test_whole_step_replays_from_one_hipgraph(labels, hand_model, conv, frames):
+    """ut_warp_backbone + ut_fuse_temporal_regress + ut_fk (deferred index checks, workspace reserved by an eager step)
+    captured into ONE hipGraph and replayed four times on alternating inputs: every replay equals the eager step on the same
+    input and no check fires.  (Round 2's whole-path replay hung: the library zeroed its tile-queue words with hipMemsetAsync,
+    and a captured memset node of >= 16 bytes fills with a stale pattern from the second replay on under ROCm 7.2
+    (tools/diag/graph_memset.py); a negative queue word then walked a persistent kernel through ~10^9 tickets.  The words are
+    zeroed by a kernel now, and the persistent loops compare tile indices as unsigned.)"""
+    eng = _native.HipEngine(synth.synthetic_state_dict(0), DEV)
+    try:
+        eng.set_conv_arithmetic(conv)
+        g = torch.Generator(device=DEV)
+        g.manual_seed(3)
+        src_a = torch.randint(0, 256, (frames * 4, 480, 636), dtype=torch.uint8, device=DEV, generator=g)
+        src_b = torch.randint(0, 256, (frames * 4, 480, 636), dtype=torch.uint8, device=DEV, generator=g)
+        plan = {k: v.cpu().numpy() for k, v in pipeline.crop_plan_on_device(labels, hand_model, range(frames), DEV).items()}
+        batch = pipeline.make_batch(plan, src_a.clone(), DEV)
+        hot = pipeline.HotPath(eng, hand_model)
+        want_a = hot.step(batch).clone()
+        batch.src.copy_(src_b)
+        want_b = hot.step(batch).clone()
+        hot.check()
+        assert not torch.equal(want_a, want_b)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(DEV)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                rec = hot.step(batch)
+        for inp, want in ((src_a, want_a), (src_b, want_b), (src_a, want_a), (src_b, want_b)):
+            batch.src.copy_(inp)
+            rec.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(rec, want)
+        hot.check()
+        del graph
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("conv", ["fp32", "split_f16"])
 def test_c5_per_rank_workload_properties(conv):
     """BASELINE config C5 per rank (1024 frames x 4 cameras x 2 hands = 2048 hand-frames, 4096 crops - what one rank of
