@@ -74,6 +74,13 @@ __device__ __forceinline__ void split_pair_p(float a, float b, unsigned& p0, uns
   p1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
 }
 
+__device__ __forceinline__ void split_pair_scaled_p(float a, float b, float s, unsigned& p0, unsigned& p1) {
+  const f16x2p h = __builtin_bit_cast(f16x2p, __builtin_amdgcn_cvt_pkrtz(a * s, b * s));
+  const float ra = __builtin_fmaf(a, s, -(float)h[0]), rb = __builtin_fmaf(b, s, -(float)h[1]);   // exact products: see conv_split.hip
+  p0 = __builtin_bit_cast(unsigned, h);
+  p1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+}
+
 template <bool SPLIT>
 __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p, int tiles_x, int tiles_per_img, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -116,17 +123,14 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
       char* rp = reinterpret_cast<char*>(smem) + (size_t)(W_FLOATS + buf * P_FLOATS) * 4 + tid * 128;
       float4 f[8];
 #pragma unroll
-      for (int g4 = 0; g4 < 8; ++g4) {
-        f[g4] = *reinterpret_cast<const float4*>(rp + ((g4 ^ sw) << 4));
-        f[g4].x *= x_scale; f[g4].y *= x_scale; f[g4].z *= x_scale; f[g4].w *= x_scale;
-      }
+      for (int g4 = 0; g4 < 8; ++g4) f[g4] = *reinterpret_cast<const float4*>(rp + ((g4 ^ sw) << 4));
 #pragma unroll
       for (int kg = 0; kg < 4; ++kg) {
         unsigned a0, a1, a2, a3, b0, b1, b2, b3;
-        split_pair_p(f[2 * kg].x, f[2 * kg].y, a0, b0);
-        split_pair_p(f[2 * kg].z, f[2 * kg].w, a1, b1);
-        split_pair_p(f[2 * kg + 1].x, f[2 * kg + 1].y, a2, b2);
-        split_pair_p(f[2 * kg + 1].z, f[2 * kg + 1].w, a3, b3);
+        split_pair_scaled_p(f[2 * kg].x, f[2 * kg].y, x_scale, a0, b0);
+        split_pair_scaled_p(f[2 * kg].z, f[2 * kg].w, x_scale, a1, b1);
+        split_pair_scaled_p(f[2 * kg + 1].x, f[2 * kg + 1].y, x_scale, a2, b2);
+        split_pair_scaled_p(f[2 * kg + 1].z, f[2 * kg + 1].w, x_scale, a3, b3);
         u32x4 a, b;
         a.x = a0; a.y = a1; a.z = a2; a.w = a3;
         b.x = b0; b.y = b1; b.z = b2; b.w = b3;

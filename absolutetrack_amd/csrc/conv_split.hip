@@ -86,6 +86,14 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsig
   p0 = __builtin_bit_cast(unsigned, h);
   p1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
 }
+// the pieces of a * s and b * s for a power of two s: the products are exact, so fma(a, s, -h) is the remainder (a * s) - h
+// in one instruction that also converts h (v_fma_mix_f32)
+__device__ __forceinline__ void split_pair_scaled(float a, float b, float s, unsigned& p0, unsigned& p1) {
+  const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a * s, b * s));
+  const float ra = __builtin_fmaf(a, s, -(float)h[0]), rb = __builtin_fmaf(b, s, -(float)h[1]);
+  p0 = __builtin_bit_cast(unsigned, h);
+  p1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+}
 __device__ __forceinline__ f16x8 frag(const unsigned (&v)[4]) {
   u32x4 t;
   t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
@@ -110,8 +118,12 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   constexpr int A_RING = HALO ? 2 : 3, W_RING = HALO ? 4 : 3;   // stages; the weight stream runs 3 chunks ahead
   constexpr int W_AHEAD = 3;
   constexpr int W_BASE = A_RING * A_STAGE;
-  constexpr int ZROW = W_BASE + W_RING * W_STAGE;          // 128 bytes of zeros (HALO: the target of out-of-image taps)
-  constexpr int SLOT = ZROW + 128;
+  constexpr int ZROW = W_BASE + W_RING * W_STAGE;          // 256 bytes of zeros (HALO: the target of out-of-image taps): a masked
+                                                           // lane reads at its valid address modulo 256, i.e. on the banks the
+                                                           // swizzle gave it - one fixed zero row made every masked lane collide
+                                                           // with whichever valid lane owned those banks (17 % of the LDS cycles)
+  static_assert(ZROW % 256 == 0, "the zero block is bank-row aligned");
+  constexpr int SLOT = ZROW + 256;
   constexpr unsigned HOOB = 0x80000000u;   // out-of-range offset that stays out of range with a slice offset added
   constexpr int NM = 3 * MI * NI;          // MFMAs (= slots) per k-step; a chunk has 2 * NM
   constexpr int UNITS = MI * 4;            // pair conversions per k-step, one per slot from CV0
@@ -219,16 +231,13 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
     const int sw_ = (row_ >> 1) & 7;                                                                 \
     char* rp_ = smem + (BUF) + row_ * 128;                                                           \
     float4 f_[8];                                                                                    \
-    _Pragma("unroll") for (int g4 = 0; g4 < 8; ++g4) {                                               \
-      f_[g4] = *reinterpret_cast<const float4*>(rp_ + ((g4 ^ sw_) << 4));                            \
-      f_[g4].x *= x_scale; f_[g4].y *= x_scale; f_[g4].z *= x_scale; f_[g4].w *= x_scale;            \
-    }                                                                                                \
+    _Pragma("unroll") for (int g4 = 0; g4 < 8; ++g4) f_[g4] = *reinterpret_cast<const float4*>(rp_ + ((g4 ^ sw_) << 4)); \
     _Pragma("unroll") for (int kg = 0; kg < 4; ++kg) {                                               \
       unsigned a0_, a1_, a2_, a3_, b0_, b1_, b2_, b3_;                                               \
-      split_pair(f_[2 * kg].x, f_[2 * kg].y, a0_, b0_);                                              \
-      split_pair(f_[2 * kg].z, f_[2 * kg].w, a1_, b1_);                                              \
-      split_pair(f_[2 * kg + 1].x, f_[2 * kg + 1].y, a2_, b2_);                                      \
-      split_pair(f_[2 * kg + 1].z, f_[2 * kg + 1].w, a3_, b3_);                                      \
+      split_pair_scaled(f_[2 * kg].x, f_[2 * kg].y, x_scale, a0_, b0_);                              \
+      split_pair_scaled(f_[2 * kg].z, f_[2 * kg].w, x_scale, a1_, b1_);                              \
+      split_pair_scaled(f_[2 * kg + 1].x, f_[2 * kg + 1].y, x_scale, a2_, b2_);                      \
+      split_pair_scaled(f_[2 * kg + 1].z, f_[2 * kg + 1].w, x_scale, a3_, b3_);                      \
       u32x4 a_, b_;                                                                                  \
       a_.x = a0_; a_.y = a1_; a_.z = a2_; a_.w = a3_;                                                \
       b_.x = b0_; b_.y = b1_; b_.z = b2_; b_.w = b3_;                                                \
@@ -336,7 +345,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
         const int row_ = lrow[i] + sh_;                                                              \
         /* the patch is already split (SP_H_CONVERT): 16-byte group 2S + fh of the first pieces, +4 for the remainders */ \
         const unsigned a_ = r_buf + (unsigned)(row_ * 128) + (unsigned)((((2 * (S) + fh) ^ ((row_ >> 1) & 7))) << 4); \
-        const unsigned a0_ = ((rmask[i] >> r_tap) & 1u) ? a_ : (unsigned)ZROW;                       \
+        const unsigned a0_ = ((rmask[i] >> r_tap) & 1u) ? a_ : (unsigned)ZROW + (a_ & 255u);         \
         const u32x4 p0_ = *reinterpret_cast<const u32x4*>(smem + a0_);                               \
         const u32x4 p1_ = *reinterpret_cast<const u32x4*>(smem + (a0_ ^ 64u));                       \
         xp[S][i][0][0] = p0_.x; xp[S][i][0][1] = p0_.y; xp[S][i][0][2] = p0_.z; xp[S][i][0][3] = p0_.w; \
@@ -358,8 +367,8 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   {                                                                                                  \
     constexpr int i_ = (U) >> 2, pr_ = (U) & 3;                                                      \
     const float4 v_ = xr[i_][pr_ >> 1];                                                              \
-    if constexpr ((pr_ & 1) == 0) split_pair(v_.x * x_scale, v_.y * x_scale, xp[SET][i_][0][pr_], xp[SET][i_][1][pr_]); \
-    else split_pair(v_.z * x_scale, v_.w * x_scale, xp[SET][i_][0][pr_], xp[SET][i_][1][pr_]);      \
+    if constexpr ((pr_ & 1) == 0) split_pair_scaled(v_.x, v_.y, x_scale, xp[SET][i_][0][pr_], xp[SET][i_][1][pr_]); \
+    else split_pair_scaled(v_.z, v_.w, x_scale, xp[SET][i_][0][pr_], xp[SET][i_][1][pr_]);          \
   }
 #define SP_PIN() __builtin_amdgcn_sched_barrier(0)
   // MFMA N of a k-step: products (weight piece, pixel piece) small terms first, accumulators round-robin inside a product
@@ -463,7 +472,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   int skip_waits = 0;
   bool prev_had_patch = false;
   int f_slice = 0;              // HALO: slice of the patch being fetched
-  if (lane < 8 && wave == 0) asm volatile("ds_write_b128 %0, %1" ::"v"(smem_addr + (unsigned)ZROW + (unsigned)lane * 16u), "v"(u32x4{0, 0, 0, 0}) : "memory");
+  if (lane < 16 && wave == 0) asm volatile("ds_write_b128 %0, %1" ::"v"(smem_addr + (unsigned)ZROW + (unsigned)lane * 16u), "v"(u32x4{0, 0, 0, 0}) : "memory");
   if constexpr (HALO) {
     SP_H_SETUP(slot);
     SP_H_MASK(slot);
@@ -668,7 +677,7 @@ hipError_t launch_split_cfg(const ConvLaunch& c, hipStream_t s) {
   const int tiles_m = (M + BM - 1) / BM;
   const int tiles_n = (c.cout_store + BN - 1) / BN;
   const int n_tiles = tiles_m * tiles_n;
-  const size_t lds = (HALO ? 2 * (size_t)320 * 128 : 3 * (size_t)BM * 128) + (HALO ? 4 : 3) * (size_t)BN * 128 + 128 + 16;
+  const size_t lds = (HALO ? 2 * (size_t)320 * 128 : 3 * (size_t)BM * 128) + (HALO ? 4 : 3) * (size_t)BN * 128 + 256 + 16;
   static std::atomic<unsigned long long> attr_set{0};
   const unsigned long long dev_bit = (c.device >= 0 && c.device < 64) ? 1ull << c.device : 0ull;
   if (!(attr_set.load(std::memory_order_relaxed) & dev_bit) || !dev_bit) {

@@ -88,11 +88,17 @@ nref = min(n_img, 4)
 xr = x[:nref].permute(0, 3, 1, 2).double().cpu()
 mid = torch.relu(torch.nn.functional.conv2d(xr, ws[0].double(), bs[0].double(), 1, 1))
 ref = torch.relu(torch.nn.functional.conv2d(mid, ws[1].double(), bs[1].double(), 1, 1) + xr).permute(0, 2, 3, 1)
-out.fill_(float("nan"))
-run("product")
-torch.cuda.synchronize()
-assert torch.isfinite(out).all()
-print(f"product: max |out - f64 block| over {nref} images = {float((out[:nref].double().cpu() - ref).abs().max()):.3e}  (|out| max {float(out.abs().max()):.2f})")
+prod = None
+for nm in ("product",):
+    out.fill_(float("nan"))
+    run(nm)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all(), nm
+    print(f"{nm}: max |out - f64 block| over {nref} images = {float((out[:nref].double().cpu() - ref).abs().max()):.3e}  (|out| max {float(out.abs().max()):.2f})")
+    if prod is None:
+        prod = out.clone()
+    else:
+        print(f"{nm} vs product: max abs diff over all images {float((out - prod).abs().max()):.3e}")
 flops = 2.0 * n_img * hw * hw * 32 * 288 * 2
 times = {k: [] for k in libs}
 for rnd in range(10):
