@@ -187,7 +187,7 @@ def main():
         # HBM bytes per launch cannot be measured by this process: they come from separate rocprofv3 --pmc passes of
         # this same command (FETCH_SIZE and WRITE_SIZE cannot share a pass), summarised by tools/pmc_traffic.py into
         # profiles/ and quoted here with their source; null when no summary matches this workload
-        traffic, traffic_source = None, None
+        traffic, traffic_source, traffic_step = None, None, None
         prof_dir = os.path.join(ROOT, "profiles")
         cands = sorted(f for f in (os.listdir(prof_dir) if os.path.isdir(prof_dir) else []) if f.endswith("_conv_traffic.json"))
         cands = [f for f in cands
@@ -195,18 +195,21 @@ def main():
         if cands and f_local == 1024 and known:
             tj = json.load(open(os.path.join(prof_dir, cands[-1])))
             traffic = tj.get("traffic_bytes_per_launch")
+            traffic_step = {"all_kernels_bytes_per_step": tj.get("step_traffic_bytes_all_kernels"),
+                            "ratio_to_algorithmic": tj.get("ratio_to_algorithmic"),
+                            "by_kernel_bytes_per_step": dict(list((tj.get("step_traffic_bytes_by_kernel") or {}).items())[:8])}
             traffic_source = (f"profiles/{cands[-1]}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `{tj.get('label', '')}` "
                               "(an earlier run of this command, not this process); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024")
         peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split_kind else PEAK_FP32_MFMA_TFLOPS
         roofline = {"bound": "mfma",
-                    "kernel": ("conv_split_kernel (both instantiations) + conv3x3_c32_patch_kernel<true> (layer1): two-piece fp16 "
-                               "splits, 3 products per k on v_mfma_f32_32x32x16_f16" if split_kind else
+                    "kernel": ("conv_split_kernel (both instantiations) + conv_block32_kernel (layer1, one launch per BasicBlock): "
+                               "two-piece fp16 splits, 3 products per k on v_mfma_f32_32x32x16_f16" if split_kind else
                                "conv_igemm_kernel (all instantiations) + conv3x3_c32_patch_kernel (layer1)"),
                     "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "peak_source": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 products per algorithmic flop" if split_kind else
                                     "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
                     "frac": round(achieved / peak, 4), "traffic": traffic,
-                    "traffic_source": traffic_source,
+                    "traffic_source": traffic_source, "traffic_whole_step": traffic_step,
                     "launches_per_step": launches // n_prof, "avg_launch_ms": round(ms / max(launches, 1), 5),
                     "flops_per_launch_avg": flops / max(launches, 1),
                     "whole_step_tflops": round(value * flops_hf / 1e12, 3)}
