@@ -25,6 +25,7 @@ VARIANTS = {
 }
 variants = [v for v in os.environ.get("BLOCK_VARIANTS", "").split(",") if v]
 ALT_SRC = os.environ.get("BLOCK_ALT_SRC")
+W4_SRC = os.path.join(ROOT, "tools", "diag", "conv_block32w_experiment.hip")      # the 4-wave experiment, timed as "w4"
 
 
 def build(name, patches, alt=None):
@@ -37,12 +38,13 @@ def build(name, patches, alt=None):
         src = f"/tmp/conv_block32_{name}.hip"
         open(src, "w").write(text)
     so = f"/tmp/libblockab_{name}.so"
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w", "-o", so, src,
-                           os.path.join(CSRC, "conv_split.hip"), os.path.join(ROOT, "tools", "diag", "block_entry.hip"), "-I", CSRC])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w", "-DBLOCK_W4", "-o", so, src,
+                           W4_SRC, os.path.join(CSRC, "conv_split.hip"), os.path.join(ROOT, "tools", "diag", "block_entry.hip"), "-I", CSRC])
     return ctypes.CDLL(so)
 
 
 libs = {"product": build("product", [])}
+libs["w4"] = libs["product"]          # the same library: the 4-wave kernel of tools/diag/conv_block32w_experiment.hip
 for v in variants:
     patches = []
     for part in v.split("+"):
@@ -78,9 +80,9 @@ out = torch.empty_like(x)
 
 def run(name):
     lib, pl = libs[name], state[name]
-    lib.block_run.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_float, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    lib.block_run.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_float, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     rc = lib.block_run(x.data_ptr(), out.data_ptr(), pl[0].data_ptr(), pl[1].data_ptr(), bias[0].data_ptr(), bias[1].data_ptr(),
-                       float(bs[0].abs().max()) * 1.0001, in_max.data_ptr(), n_img, hw)
+                       float(bs[0].abs().max()) * 1.0001, in_max.data_ptr(), n_img, hw, int(name == "w4"))
     assert rc == 0, rc
 
 
@@ -89,7 +91,7 @@ xr = x[:nref].permute(0, 3, 1, 2).double().cpu()
 mid = torch.relu(torch.nn.functional.conv2d(xr, ws[0].double(), bs[0].double(), 1, 1))
 ref = torch.relu(torch.nn.functional.conv2d(mid, ws[1].double(), bs[1].double(), 1, 1) + xr).permute(0, 2, 3, 1)
 prod = None
-for nm in ("product",):
+for nm in ("product", "w4"):
     out.fill_(float("nan"))
     run(nm)
     torch.cuda.synchronize()

@@ -17,8 +17,12 @@ extern "C" int block_pack(const float* w, int which, uint16_t* out) {       // w
   return (int)(ut::pack_split_weights(w, 128, 288, scale, out) != (size_t)2 * 128 * 288);
 }
 
+#ifdef BLOCK_W4
+namespace ut { hipError_t launch_conv_block32w(const BlockLaunch& b, hipStream_t s); }
+#endif
+
 extern "C" int block_run(const float* in, float* out, const void* w1s, const void* w2s, const float* b1, const float* b2,
-                         float bmax1, const unsigned* in_max, int n_img, int hw) {
+                         float bmax1, const unsigned* in_max, int n_img, int hw, int four_waves) {
   ut::BlockLaunch b{};
   b.in = in; b.out = out; b.w1_split = w1s; b.w2_split = w2s; b.unscale_w1 = g_unscale[0]; b.unscale_w2 = g_unscale[1];
   b.bias1 = b1; b.bias2 = b2; b.wsum1 = g_wsum1; b.bmax1 = bmax1; b.in_max = in_max; b.out_max = nullptr; b.status = nullptr;
@@ -27,5 +31,8 @@ extern "C" int block_run(const float* in, float* out, const void* w1s, const voi
   if (!cnt) (void)hipMalloc((void**)&cnt, 4);
   (void)hipMemsetAsync(cnt, 0, 4, 0);
   b.tile_counter = cnt;
+#ifdef BLOCK_W4
+  if (four_waves) return (int)ut::launch_conv_block32w(b, 0);
+#endif
   return (int)ut::launch_conv_block32(b, 0);
 }

@@ -15,6 +15,8 @@
 #include "ut_kernels.h"
 
 namespace ut {
+bool conv_block32w_applicable(const BlockLaunch& b);
+hipError_t launch_conv_block32w(const BlockLaunch& b, hipStream_t s);
 namespace {
 
 typedef float f32x16w __attribute__((ext_vector_type(16)));
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(64 * W_WAVES, 1) void conv_block32w_kernel(BlockLau
       const int gy = y0 - 2 + py, gx = x0 - 2 + px;
       const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
       const unsigned off = ok ? (unsigned)((((row0 + gy) * W + gx) * C + 4 * c4) * 4) : W_OOB;
-      w_dma(in_words, smem_addr + (unsigned)(R_OFF + buf * W_R_BYTES + k * 1024), off);
+      w_dma(in_words, (unsigned)__builtin_amdgcn_readfirstlane((int)(smem_addr + (unsigned)(R_OFF + buf * W_R_BYTES + k * 1024))), off);
     }
   };
 
@@ -253,6 +255,13 @@ __global__ __launch_bounds__(64 * W_WAVES, 1) void conv_block32w_kernel(BlockLau
   for (;;) {
     const bool has_next = (unsigned)next < (unsigned)n_tiles;
     char* region = smem + R_OFF + cur * W_R_BYTES;
+    // per-tile opaque copies of the row bases: the per-tap address arithmetic then stays inside the tile loop instead of being
+    // hoisted into ~100 registers that live across it
+    int p1b[WU1], p2b[WU2];
+#pragma unroll
+    for (int j = 0; j < WU1; ++j) { p1b[j] = p1base[j]; asm volatile("" : "+v"(p1b[j])); }
+#pragma unroll
+    for (int j = 0; j < WU2; ++j) { p2b[j] = p2base[j]; asm volatile("" : "+v"(p2b[j])); }
     // ---- A: residuals of my two output blocks from the fp32 patch
     u32x4w rr[WU2][4];
 #pragma unroll
@@ -285,12 +294,14 @@ __global__ __launch_bounds__(64 * W_WAVES, 1) void conv_block32w_kernel(BlockLau
     {
       u32x4w pxA[WU1][2], pxB[WU1][2];
 #pragma unroll
-      for (int j = 0; j < WU1; ++j) W_READ_PX(pxA[j], region, p1base[j], WP, 0, 0);
+      for (int j = 0; j < WU1; ++j) W_READ_PX(pxA[j], region, p1b[j], WP, 0, 0);
+#pragma unroll
+      for (int j = 0; j < WU1; ++j) asm volatile("" : "+a"(acc[j]));      // initialised before the first MFMA, not between them
       W_MFMA_LEAD();
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
-        for (int j = 0; j < WU1; ++j) W_READ_PX(pxB[j], region, p1base[j], WP, tap, 1);
+        for (int j = 0; j < WU1; ++j) W_READ_PX(pxB[j], region, p1b[j], WP, tap, 1);
         if (has_next && 2 * tap < W_MAXP) issue_piece(2 * tap, n_row0, n_y0, n_x0, cur ^ 1);
         W_PIN();
 #pragma unroll
@@ -298,7 +309,7 @@ __global__ __launch_bounds__(64 * W_WAVES, 1) void conv_block32w_kernel(BlockLau
         W_PIN();
         if (tap < 8) {
 #pragma unroll
-          for (int j = 0; j < WU1; ++j) W_READ_PX(pxA[j], region, p1base[j], WP, tap + 1, 0);
+          for (int j = 0; j < WU1; ++j) W_READ_PX(pxA[j], region, p1b[j], WP, tap + 1, 0);
         }
         if (has_next && 2 * tap + 1 < W_MAXP) issue_piece(2 * tap + 1, n_row0, n_y0, n_x0, cur ^ 1);
         W_PIN();
@@ -365,13 +376,15 @@ __global__ __launch_bounds__(64 * W_WAVES, 1) void conv_block32w_kernel(BlockLau
     DST[1] = *reinterpret_cast<const u32x4w*>(w2_bytes + (((TAP) * 2 + (S)) * 2 + 1) * 1024);        \
   }
 #pragma unroll
-      for (int j = 0; j < WU2; ++j) W_READ_PX(pxA[j], region, p2base[j], WI, 0, 0);
+      for (int j = 0; j < WU2; ++j) W_READ_PX(pxA[j], region, p2b[j], WI, 0, 0);
       W_READ_W(wA, 0, 0);
+#pragma unroll
+      for (int j = 0; j < WU2; ++j) asm volatile("" : "+a"(acc2[j]));
       W_MFMA_LEAD();
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
-        for (int j = 0; j < WU2; ++j) W_READ_PX(pxB[j], region, p2base[j], WI, tap, 1);
+        for (int j = 0; j < WU2; ++j) W_READ_PX(pxB[j], region, p2b[j], WI, tap, 1);
         W_READ_W(wB, tap, 1);
         W_PIN();
 #pragma unroll
@@ -379,7 +392,7 @@ __global__ __launch_bounds__(64 * W_WAVES, 1) void conv_block32w_kernel(BlockLau
         W_PIN();
         if (tap < 8) {
 #pragma unroll
-          for (int j = 0; j < WU2; ++j) W_READ_PX(pxA[j], region, p2base[j], WI, tap + 1, 0);
+          for (int j = 0; j < WU2; ++j) W_READ_PX(pxA[j], region, p2b[j], WI, tap + 1, 0);
           W_READ_W(wA, tap + 1, 0);
         } else {
           // the next patch has had conv1 and conv2 to land; nothing else of mine is in flight, and this sits in front of
