@@ -28,6 +28,9 @@ ALT_SRC = os.environ.get("BLOCK_ALT_SRC")
 W4_SRC = os.path.join(ROOT, "tools", "diag", "conv_block32w_experiment.hip")      # the 4-wave experiment, timed as "w4"
 
 
+STAMPS = os.environ.get("BLOCK_STAMPS") == "1"      # w4 built with -DW4_STAMPS: phase stamps of every workgroup's 4th tile
+
+
 def build(name, patches, alt=None):
     src = alt or os.path.join(CSRC, "conv_block32.hip")
     if patches:
@@ -38,7 +41,7 @@ def build(name, patches, alt=None):
         src = f"/tmp/conv_block32_{name}.hip"
         open(src, "w").write(text)
     so = f"/tmp/libblockab_{name}.so"
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w", "-DBLOCK_W4", "-o", so, src,
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w", "-DBLOCK_W4", *(["-DW4_STAMPS"] if STAMPS else []), "-o", so, src,
                            W4_SRC, os.path.join(CSRC, "conv_split.hip"), os.path.join(ROOT, "tools", "diag", "block_entry.hip"), "-I", CSRC])
     return ctypes.CDLL(so)
 
@@ -101,6 +104,18 @@ for nm in ("product", "w4"):
         prod = out.clone()
     else:
         print(f"{nm} vs product: max abs diff over all images {float((out - prod).abs().max()):.3e}")
+if STAMPS:
+    run("w4")
+    buf = np.zeros(256 * 8, np.uint64)
+    assert libs["w4"].block_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+    st = buf.reshape(256, 8)[:, :6].astype(np.int64)
+    d = np.diff(st, axis=1)
+    names = ["residual reads + convert (S1, S2)", "conv1 MFMA loop", "epilogue 1 + S3 + I writes + S4", "conv2 MFMA loop", "epilogue 2 (stores)"]
+    print("w4 phase stamps, 4th tile of every workgroup (cycles: median / p10 / p90):")
+    for i, nm in enumerate(names):
+        print(f"   {nm:40s} {int(np.median(d[:, i])):7d} {int(np.percentile(d[:, i], 10)):7d} {int(np.percentile(d[:, i], 90)):7d}")
+    print(f"   {'tile total':40s} {int(np.median(st[:, 5] - st[:, 0])):7d}")
+    sys.exit(0)
 flops = 2.0 * n_img * hw * hw * 32 * 288 * 2
 times = {k: [] for k in libs}
 for rnd in range(10):

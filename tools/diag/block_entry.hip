@@ -21,6 +21,13 @@ extern "C" int block_pack(const float* w, int which, uint16_t* out) {       // w
 namespace ut { hipError_t launch_conv_block32w(const BlockLaunch& b, hipStream_t s); }
 #endif
 
+static int* g_dbg = nullptr;            // stamp buffer of the -DW4_STAMPS build (8 x u64 per workgroup)
+extern "C" int block_stamps(unsigned long long* host) {      // copies the last w4 launch's stamps (256 x 8 u64)
+  if (!g_dbg) return 1;
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpy(host, g_dbg, 256 * 8 * 8, hipMemcpyDeviceToHost);
+}
+
 extern "C" int block_run(const float* in, float* out, const void* w1s, const void* w2s, const float* b1, const float* b2,
                          float bmax1, const unsigned* in_max, int n_img, int hw, int four_waves) {
   ut::BlockLaunch b{};
@@ -32,7 +39,11 @@ extern "C" int block_run(const float* in, float* out, const void* w1s, const voi
   (void)hipMemsetAsync(cnt, 0, 4, 0);
   b.tile_counter = cnt;
 #ifdef BLOCK_W4
-  if (four_waves) return (int)ut::launch_conv_block32w(b, 0);
+  if (four_waves) {
+    if (!g_dbg) { (void)hipMalloc((void**)&g_dbg, 256 * 8 * 8); (void)hipMemset(g_dbg, 0, 256 * 8 * 8); }
+    b.status = g_dbg;
+    return (int)ut::launch_conv_block32w(b, 0);
+  }
 #endif
   return (int)ut::launch_conv_block32(b, 0);
 }

@@ -107,7 +107,9 @@ __global__ __launch_bounds__(64 * W_WAVES, 1) void conv_block32w_kernel(BlockLau
   {
     bool ok;
     split_act_scale(p.in_max, x_scale, x_unscale, ok);
+#ifndef W4_STAMPS
     if (!ok && tid == 0 && blockIdx.x == 0 && p.status) atomicOr(p.status, UT_SPLIT_RANGE);
+#endif
     const float xmax = ok ? __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)*p.in_max)) : 0.f;
     w_pow2_for(xmax * p.wsum1 + p.bmax1, i_scale, i_unscale);
   }
@@ -250,11 +252,20 @@ __global__ __launch_bounds__(64 * W_WAVES, 1) void conv_block32w_kernel(BlockLau
     W_MFMA1(ACC, WCL, W0, PX[0]);                                                                    \
   }
 #define W_MFMA_LEAD() asm volatile("s_nop 3")
-#define W_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 3")
+#define W_MFMA_DRAIN3(A, B, C) asm volatile("s_nop 15\n\ts_nop 3" : "+a"(A), "+a"(B), "+a"(C))
+#define W_MFMA_DRAIN2(A, B) asm volatile("s_nop 15\n\ts_nop 3" : "+a"(A), "+a"(B))
 
+#ifdef W4_STAMPS
+  int tile_no = 0;
+  unsigned long long st_[8];
+#define W_STAMP(I) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_[I]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define W_STAMP(I)
+#endif
   for (;;) {
     const bool has_next = (unsigned)next < (unsigned)n_tiles;
     char* region = smem + R_OFF + cur * W_R_BYTES;
+    W_STAMP(0)
     // per-tile opaque copies of the row bases: the per-tap address arithmetic then stays inside the tile loop instead of being
     // hoisted into ~100 registers that live across it
     int p1b[WU1], p2b[WU2];
@@ -276,6 +287,7 @@ __global__ __launch_bounds__(64 * W_WAVES, 1) void conv_block32w_kernel(BlockLau
     if (tid + 256 < WP_PIX) convert_row(region, tid + 256);
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();            // S2
+    W_STAMP(1)
 
     // ---- C: conv1 on my three blocks, weights from registers; the next patch is requested piece by piece under it
     const int ticket = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, q_rsrc, q_off, 0, 0);
@@ -298,27 +310,33 @@ __global__ __launch_bounds__(64 * W_WAVES, 1) void conv_block32w_kernel(BlockLau
 #pragma unroll
       for (int j = 0; j < WU1; ++j) asm volatile("" : "+a"(acc[j]));      // initialised before the first MFMA, not between them
       W_MFMA_LEAD();
+      // One wave per SIMD issues in order: whatever is not an MFMA must sit BETWEEN the MFMAs (each leaves ~24 idle issue
+      // cycles), not between groups of them.  Block j's fragments of the NEXT k-step are requested right behind block j's three
+      // MFMAs of this one; a patch piece of the next tile rides behind the first block.
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-#pragma unroll
-        for (int j = 0; j < WU1; ++j) W_READ_PX(pxB[j], region, p1b[j], WP, tap, 1);
+        W_MFMA3(acc[0], "a", w1r[tap][0][0], w1r[tap][0][1], pxA[0]); W_PIN();
+        W_READ_PX(pxB[0], region, p1b[0], WP, tap, 1);
         if (has_next && 2 * tap < W_MAXP) issue_piece(2 * tap, n_row0, n_y0, n_x0, cur ^ 1);
         W_PIN();
-#pragma unroll
-        for (int j = 0; j < WU1; ++j) W_MFMA3(acc[j], "a", w1r[tap][0][0], w1r[tap][0][1], pxA[j]);
-        W_PIN();
-        if (tap < 8) {
-#pragma unroll
-          for (int j = 0; j < WU1; ++j) W_READ_PX(pxA[j], region, p1b[j], WP, tap + 1, 0);
-        }
+        W_MFMA3(acc[1], "a", w1r[tap][0][0], w1r[tap][0][1], pxA[1]); W_PIN();
+        W_READ_PX(pxB[1], region, p1b[1], WP, tap, 1); W_PIN();
+        W_MFMA3(acc[2], "a", w1r[tap][0][0], w1r[tap][0][1], pxA[2]); W_PIN();
+        W_READ_PX(pxB[2], region, p1b[2], WP, tap, 1); W_PIN();
+        W_MFMA3(acc[0], "a", w1r[tap][1][0], w1r[tap][1][1], pxB[0]); W_PIN();
+        if (tap < 8) W_READ_PX(pxA[0], region, p1b[0], WP, tap + 1, 0);
         if (has_next && 2 * tap + 1 < W_MAXP) issue_piece(2 * tap + 1, n_row0, n_y0, n_x0, cur ^ 1);
         W_PIN();
-#pragma unroll
-        for (int j = 0; j < WU1; ++j) W_MFMA3(acc[j], "a", w1r[tap][1][0], w1r[tap][1][1], pxB[j]);
+        W_MFMA3(acc[1], "a", w1r[tap][1][0], w1r[tap][1][1], pxB[1]); W_PIN();
+        if (tap < 8) W_READ_PX(pxA[1], region, p1b[1], WP, tap + 1, 0);
+        W_PIN();
+        W_MFMA3(acc[2], "a", w1r[tap][1][0], w1r[tap][1][1], pxB[2]); W_PIN();
+        if (tap < 8) W_READ_PX(pxA[2], region, p1b[2], WP, tap + 1, 0);
         W_PIN();
       }
     }
-    W_MFMA_DRAIN();
+    W_STAMP(2)
+    W_MFMA_DRAIN3(acc[0], acc[1], acc[2]);
     // BatchNorm (folded) + ReLU; intermediate pixels outside the image are conv2's zero padding
     unsigned ip0[WU1][8], ip1[WU1][8];
 #pragma unroll
@@ -354,6 +372,7 @@ __global__ __launch_bounds__(64 * W_WAVES, 1) void conv_block32w_kernel(BlockLau
     if (tid == 0) slot_write(cur, grid + ticket);
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();            // S4: the intermediate is complete
+    W_STAMP(3)
 
     // ---- D: conv2 on my two blocks; one weight-fragment read from LDS serves both
     f32x16w acc2[WU2];
@@ -383,30 +402,31 @@ __global__ __launch_bounds__(64 * W_WAVES, 1) void conv_block32w_kernel(BlockLau
       W_MFMA_LEAD();
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-#pragma unroll
-        for (int j = 0; j < WU2; ++j) W_READ_PX(pxB[j], region, p2b[j], WI, tap, 1);
+        W_MFMA3(acc2[0], "v", wA[0], wA[1], pxA[0]); W_PIN();
+        W_READ_PX(pxB[0], region, p2b[0], WI, tap, 1);
         W_READ_W(wB, tap, 1);
         W_PIN();
-#pragma unroll
-        for (int j = 0; j < WU2; ++j) W_MFMA3(acc2[j], "v", wA[0], wA[1], pxA[j]);
+        W_MFMA3(acc2[1], "v", wA[0], wA[1], pxA[1]); W_PIN();
+        W_READ_PX(pxB[1], region, p2b[1], WI, tap, 1);
+        if (tap < 8) W_READ_W(wA, tap + 1, 0);          // wA is free from here: three groups ahead of its next use
         W_PIN();
+        W_MFMA3(acc2[0], "v", wB[0], wB[1], pxB[0]); W_PIN();
         if (tap < 8) {
-#pragma unroll
-          for (int j = 0; j < WU2; ++j) W_READ_PX(pxA[j], region, p2b[j], WI, tap + 1, 0);
-          W_READ_W(wA, tap + 1, 0);
+          W_READ_PX(pxA[0], region, p2b[0], WI, tap + 1, 0);
         } else {
           // the next patch has had conv1 and conv2 to land; nothing else of mine is in flight, and this sits in front of
           // the tile's stores (vmcnt counts stores too: behind them the wait would cost a write round trip)
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         W_PIN();
-#pragma unroll
-        for (int j = 0; j < WU2; ++j) W_MFMA3(acc2[j], "v", wB[0], wB[1], pxB[j]);
+        W_MFMA3(acc2[1], "v", wB[0], wB[1], pxB[1]); W_PIN();
+        if (tap < 8) W_READ_PX(pxA[1], region, p2b[1], WI, tap + 1, 0);
         W_PIN();
       }
 #undef W_READ_W
     }
-    W_MFMA_DRAIN();
+    W_STAMP(4)
+    W_MFMA_DRAIN2(acc2[0], acc2[1]);
 #pragma unroll
     for (int j = 0; j < WU2; ++j) {
       const int m = (c_row0 + c_y0 + oy2[j]) * W + c_x0 + ox2[j];
@@ -421,6 +441,14 @@ __global__ __launch_bounds__(64 * W_WAVES, 1) void conv_block32w_kernel(BlockLau
         __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, (unsigned)(m * C + 8 * g4 + 4 * fh) * 4u, 0, 0);
       }
     }
+#ifdef W4_STAMPS
+    W_STAMP(5)
+    if (tile_no == 3 && tid == 0) {
+      unsigned long long* d = reinterpret_cast<unsigned long long*>(p.status) + blockIdx.x * 8;
+      for (int i = 0; i < 6; ++i) d[i] = st_[i];
+    }
+    ++tile_no;
+#endif
     if (!has_next) break;
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();            // S0: the next patch has landed for every wave; conv2's reads of this region are done
@@ -436,7 +464,8 @@ __global__ __launch_bounds__(64 * W_WAVES, 1) void conv_block32w_kernel(BlockLau
 #undef W_MFMA3
 #undef W_MFMA1
 #undef W_MFMA_LEAD
-#undef W_MFMA_DRAIN
+#undef W_MFMA_DRAIN3
+#undef W_MFMA_DRAIN2
 }
 
 bool conv_block32w_applicable(const BlockLaunch& b) {
