@@ -47,6 +47,9 @@ hipError_t launch_splitk_finish(const float* slabs, int n_splits, int m, int cou
 // the same convolution on the fp16 matrix cores from two-piece splits of both operands (conv_split.hip)
 bool conv_split_applicable(const ConvLaunch& c);
 hipError_t launch_conv_split(const ConvLaunch& c, hipStream_t s);
+// 3x3 stride-1 64 -> 64 channels with the weights resident in registers, one wave per SIMD (conv_c64r.hip): same results
+bool conv_c64r_applicable(const ConvLaunch& c);
+hipError_t launch_conv_c64r(const ConvLaunch& c, hipStream_t s);
 size_t pack_split_weights(const float* w, int cout_pad, int k_pad, float scale, uint16_t* out);
 float split_weight_scale(const float* w, size_t n);
 // One 32 -> 32 -> 32 channel BasicBlock (stride 1, no shortcut convolution) in one launch, split-fp16 arithmetic

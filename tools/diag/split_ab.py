@@ -52,12 +52,15 @@ def build(name, patches, flags=(), alt=None):
         open(src, "w").write(text)
     so = f"/tmp/libsplitab_{name}.so"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w", *flags, "-o", so,
-                           os.path.join(CSRC, "conv_igemm.hip"), os.path.join(CSRC, "conv_patch.hip"), src,
+                           os.path.join(CSRC, "conv_igemm.hip"), os.path.join(CSRC, "conv_patch.hip"), os.path.join(CSRC, "conv_c64r.hip"), src,
                            os.path.join(ROOT, "tools", "diag", "split_entry.hip"), "-I", CSRC])
     return ctypes.CDLL(so)
 
 
-lib = build("product", [])
+if os.environ.get("C64_STAMPS") == "1":      # phase stamps of conv_c64r.hip (third tile, second run of every workgroup)
+    lib = build("stamps", [], flags=["-DC64_STAMPS"])
+else:
+    lib = build("product", [])
 vlibs = {}
 for v in variants:
     patches, flags = [], []
@@ -96,6 +99,15 @@ def run(mode, lib=lib):
     assert rc == 0, rc
 
 
+if os.environ.get("C64_STAMPS") == "1":
+    run(1)
+    buf = np.zeros(256 * 8, np.uint64)
+    assert lib.conv_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+    st = buf.reshape(256, 8)[:, :5].astype(np.int64)
+    d = np.diff(st, axis=1)
+    for i, nm in enumerate(["MFMA loop of the run (216 MFMAs)", "vmcnt wait (next patch landed)", "epilogue (residual, stores)", "B1 + split of the next patch + B2"]):
+        print(f"   {nm:40s} median {int(np.median(d[:, i])):7d}  p10 {int(np.percentile(d[:, i], 10)):7d}  p90 {int(np.percentile(d[:, i], 90)):7d}")
+    sys.exit(0)
 nref = min(n_img, 6)
 ref = torch.nn.functional.conv2d(x[:nref].permute(0, 3, 1, 2).double().cpu(), w_oihw.double(), bias[:cout].double(), stride, ksize // 2)
 ref = torch.relu(ref.permute(0, 2, 3, 1) + res[:nref].double().cpu())

@@ -11,6 +11,13 @@ extern "C" int split_pack(const float* w, int cout_pad, int k_pad, uint16_t* out
   return (int)(ut::pack_split_weights(w, cout_pad, k_pad, scale, out) != (size_t)2 * cout_pad * k_pad);
 }
 
+static int* g_dbg = nullptr;            // stamp buffer of -DC64_STAMPS builds (8 x u64 per workgroup)
+extern "C" int conv_stamps(unsigned long long* host) {
+  if (!g_dbg) return 1;
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpy(host, g_dbg, 256 * 8 * 8, hipMemcpyDeviceToHost);
+}
+
 extern "C" int conv_diag2(const float* in, const float* w, const void* w_split, const float* bias, const float* res,
                           float* out, int n_img, int hw, int cin, int cout, int ksize, int stride, int relu, int mode) {
   ut::ConvLaunch c{};
@@ -26,6 +33,10 @@ extern "C" int conv_diag2(const float* in, const float* w, const void* w_split, 
   (void)hipMemsetAsync(cnt, 0, 4, 0);
   c.tile_counter = cnt;
   if (!mode) c.w_split = nullptr;
+#ifdef C64_STAMPS
+  if (!g_dbg) { (void)hipMalloc((void**)&g_dbg, 256 * 8 * 8); (void)hipMemset(g_dbg, 0, 256 * 8 * 8); }
+  c.status = g_dbg;
+#endif
   // mode 1: the split-fp16 kernel for the shape (conv_split.hip, or the split instantiation of the layer1 patch kernel)
   return (int)(mode && ut::conv_split_applicable(c) ? ut::launch_conv_split(c, 0) : ut::launch_conv_igemm(c, 0));
 }
