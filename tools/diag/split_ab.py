@@ -41,7 +41,7 @@ variants = [v for v in os.environ.get("SPLIT_VARIANTS", "").split(",") if v]
 ALT_SRC = os.environ.get("SPLIT_ALT_SRC")
 
 
-def build(name, patches, flags=(), alt=None):
+def build(name, patches, flags=(), alt=None, c64=None):
     src = alt or os.path.join(CSRC, "conv_split.hip")
     if patches:
         text = open(src).read()
@@ -50,9 +50,10 @@ def build(name, patches, flags=(), alt=None):
             text = text.replace(old, new)
         src = f"/tmp/conv_split_{name}.hip"
         open(src, "w").write(text)
+    c64_src = c64 or os.path.join(CSRC, "conv_c64r.hip")
     so = f"/tmp/libsplitab_{name}.so"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w", *flags, "-o", so,
-                           os.path.join(CSRC, "conv_igemm.hip"), os.path.join(CSRC, "conv_patch.hip"), os.path.join(CSRC, "conv_c64r.hip"), src,
+                           os.path.join(CSRC, "conv_igemm.hip"), os.path.join(CSRC, "conv_patch.hip"), c64_src, src,
                            os.path.join(ROOT, "tools", "diag", "split_entry.hip"), "-I", CSRC])
     return ctypes.CDLL(so)
 
@@ -72,6 +73,10 @@ for v in variants:
     vlibs[v] = build(v.replace("=", "_"), patches, flags)
 if ALT_SRC:
     vlibs["alt"] = build("alt", [], alt=ALT_SRC)
+# C64_ALT_SRCS=<path>,<path>: other versions of conv_c64r.hip (with the product conv_split.hip), timed beside the product as c64:<file>
+for path in [q for q in os.environ.get("C64_ALT_SRCS", "").split(",") if q]:
+    nm = os.path.splitext(os.path.basename(path))[0]
+    vlibs["c64:" + nm] = build("c64_" + nm, [], c64=path)
 dev = "cuda:0"
 torch.manual_seed(0)
 ho = (hw + 2 * (ksize // 2) - ksize) // stride + 1
@@ -137,4 +142,4 @@ for rnd in range(10):
 for name, _m, _l in cases:
     t = times[name]
     med, mn = statistics.median(t), min(t)
-    print(f"{name:14s} median {med*1e3:8.1f} us ({flops/med/1e9:6.1f} TF-equivalent)   min {mn*1e3:8.1f} us ({flops/mn/1e9:6.1f})")
+    print(f"{name:22s} median {med*1e3:8.1f} us ({flops/med/1e9:6.1f} TF-equivalent)   min {mn*1e3:8.1f} us ({flops/mn/1e9:6.1f})")

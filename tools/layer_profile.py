@@ -45,7 +45,7 @@ head = [("fus0 144->108", 144 * 108), ("fus1 108->72", 108 * 72), ("fus2 72->72"
         ("reg1.conv1 76", 9 * 76 * 76), ("reg1.conv2 76", 9 * 76 * 76)]
 seq += [(nm, 2 * mac * 36 * s) for nm, mac in head]
 
-is_conv = lambda r: any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_c32_patch", "conv_split", "conv_block32"))
+is_conv = lambda r: any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_c32_patch", "conv_split", "conv_block32", "conv_c64r"))
 
 
 def label(name):
@@ -54,6 +54,8 @@ def label(name):
         return "split f16 " + "x".join(args.split(", ")[:2])
     if "conv_block32" in name:
         return "fused block 12x16 split f16"
+    if "conv_c64r" in name:
+        return "split f16 256x64 reg weights"
     if "conv3x3_c32_patch" in name:
         return "halo patch 16x24" + (" split f16" if args == "true" else "")
     return "fp32 " + "x".join(args.split(", ")[:2])
@@ -67,9 +69,9 @@ for (nm, fl), r in zip(seq, last):
     a = agg.setdefault(nm, [0, 0.0, 0.0, tile])
     a[0] += 1; a[1] += dur(r); a[2] += fl
 tot_t = sum(a[1] for a in agg.values()); tot_f = sum(a[2] for a in agg.values())
-print(f"{'conv':28s} {'kernel':26s} {'n':>3s} {'total us':>10s} {'TFLOP/s':>8s} {'% of conv time':>8s}")
+print(f"{'conv':28s} {'kernel':28s} {'n':>3s} {'total us':>10s} {'TFLOP/s':>8s} {'% of conv time':>8s}")
 for nm, (n, t, fl, tile) in agg.items():
-    print(f"{nm:28s} {tile:26s} {n:3d} {t:10.1f} {fl/t/1e6:8.1f} {100*t/tot_t:8.2f}")
+    print(f"{nm:28s} {tile:28s} {n:3d} {t:10.1f} {fl/t/1e6:8.1f} {100*t/tot_t:8.2f}")
 print(f"conv total {tot_t/1e3:.3f} ms, {tot_f/tot_t/1e6:.1f} TFLOP/s")
 t0 = int(last[0]["Start_Timestamp"])
 others = collections.Counter()
