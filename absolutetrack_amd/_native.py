@@ -23,7 +23,7 @@ EXPORTS = (
     "ut_reset_memory", "ut_get_memory", "ut_fk", "ut_gen_crop_cameras", "ut_gen_crop_matrices",
     "ut_resample_homography", "ut_keypoint_metrics", "ut_profile_begin", "ut_profile_end", "ut_profile_end_by_kind",
     "ut_set_index_checks", "ut_poll_status", "ut_warp_backbone", "ut_set_latency_mode", "ut_set_conv_arithmetic",
-    "ut_set_backbone_lanes", "ut_status_snapshot", "ut_warp_map", "ut_set_block_fusion",
+    "ut_set_backbone_lanes", "ut_status_snapshot", "ut_warp_map", "ut_set_block_fusion", "ut_set_resident_weights",
 )
 
 UT_MODE_KNOWN, UT_MODE_UNKNOWN = 0, 1
@@ -99,6 +99,8 @@ def load_library() -> ctypes.CDLL:
     lib.ut_set_backbone_lanes.argtypes = [vp, i32]
     lib.ut_set_block_fusion.restype = i32
     lib.ut_set_block_fusion.argtypes = [vp, i32]
+    lib.ut_set_resident_weights.restype = i32
+    lib.ut_set_resident_weights.argtypes = [vp, i32]
     lib.ut_warp_map.restype = i32
     lib.ut_warp_map.argtypes = [vp, vp, vp, i32, i32, vp, vp]
     lib.ut_status_snapshot.restype = i32
@@ -428,6 +430,11 @@ class HipEngine:
     def set_block_fusion(self, on: bool):
         """Split-fp16 mode: layer1's BasicBlocks as one launch each (default) or as two convolution launches (A/B tests)."""
         self._check(self.lib.ut_set_block_fusion(self._h, int(bool(on))), "ut_set_block_fusion")
+
+    def set_resident_weights(self, on: bool):
+        """Split-fp16 mode: layer2's 64 -> 64 convolutions with the weights resident in registers (default) or through the chunked
+        kernel of the other layers (A/B tests; same bits)."""
+        self._check(self.lib.ut_set_resident_weights(self._h, int(bool(on))), "ut_set_resident_weights")
 
     def set_latency_mode(self, on: bool):
         """Few-crop launches split K across workgroups (per-frame tracking); results then agree with the default mode to

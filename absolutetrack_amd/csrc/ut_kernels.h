@@ -36,6 +36,7 @@ struct ConvLaunch {
   int device;          // HIP device the launch goes to (the dynamic-LDS attribute is set once per device)
   int num_cu;          // compute units of the device (persistent grid sizing)
   unsigned* tile_counter;   // device word, zero before the launch: dynamic tile queue of the persistent grid
+  int no_resident;     // split kernels: 1 = never the register-resident-weights kernel (ut_set_resident_weights(h, 0))
   int splits;          // > 1 (latency mode): K is cut in `splits` equal chunk ranges, out = [splits][M][cout_store] slabs;
                        // 1 = latency mode without a split (prefers small tiles); 0 = throughput dispatch
 };

@@ -120,6 +120,11 @@ int ut_set_conv_arithmetic(ut_handle h, int mode);
  * so the two forms agree to the split arithmetic's rounding (~1e-7 relative), not bit for bit.  0 is for A/B tests. */
 int ut_set_block_fusion(ut_handle h, int on);
 
+/* Split-fp16 mode only: layer2's stride-1 64 -> 64 convolutions through the kernel that keeps the weights of an output block in
+ * registers (csrc/conv_c64r.hip; 1 = default) or through the chunked kernel every other layer uses (0).  Same products in the
+ * same order per output element: the two give the same bits; 0 is for A/B tests. */
+int ut_set_resident_weights(ut_handle h, int on);
+
 /* Latency mode for calls on a handful of crops (the per-frame tracker): convolutions whose launch has far fewer tiles
  * than the chip has CUs split K across workgroups and add the partial sums in a fixed order.  Deterministic, but not
  * the unsplit kernel's summation order: results agree with the default mode to fp32 rounding (~1e-6 relative), not

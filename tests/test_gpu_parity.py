@@ -105,6 +105,25 @@ def test_split_f16_backbone_matches_oracle(engine, split_engine):
     assert torch.equal(split_engine.backbone(_dev(crops)).cpu(), got)       # deterministic
 
 
+@pytest.mark.parametrize("n_crops", [1, 5, 37, 300])
+def test_split_f16_resident_weight_kernel_gives_the_chunked_kernels_bits(split_engine, n_crops):
+    """conv_c64r.hip (layer2's five stride-1 64 -> 64 convolutions, weights resident in registers, one wave per SIMD) against
+    conv_split_kernel<256, 64, 8, 1, true> on the same tensors: the same products in the same order per output element, so the
+    backbone's features are equal bit for bit.  1 crop = 2.25 tiles (fewer tiles than workgroups, a ragged last tile, image
+    borders inside a tile), 5 crops = 11.25 tiles, 37 = 83.25, 300 crops = 675 tiles on 256 persistent workgroups (2.6 tiles each:
+    the three-buffer patch ring wraps, workgroups with two and with three tiles)."""
+    crops = _dev(synth.synthetic_crops(n_crops, seed=23 + n_crops))
+    resident = split_engine.backbone(crops)
+    split_engine.set_resident_weights(False)
+    try:
+        chunked = split_engine.backbone(crops)
+    finally:
+        split_engine.set_resident_weights(True)
+    assert torch.isfinite(resident).all()
+    assert torch.equal(resident, chunked)
+    assert torch.equal(split_engine.backbone(crops), resident)       # deterministic
+
+
 def test_split_f16_fused_layer1_blocks_match_the_two_launch_form(engine, split_engine):
     """conv_block32.hip (layer1's BasicBlocks as one launch each, the intermediate in LDS) against the same arithmetic as two
     convolution launches per block: the forms differ only in the intermediate's power-of-two scale (a bound there, the
