@@ -19,6 +19,8 @@
 // asm so that the operand classes are this file's choice (hipcc keeps MFMA A/B operands in the vector half and spills,
 // DESIGN.md 4c); what the compiler then does not know - the wait states between an asm MFMA and other instructions that
 // touch its registers - is in C64_LEAD / C64_DRAIN.
+// The pixels are the MFMAs' first operand, the weights the second: a lane's accumulators are one output channel of sixteen pixels,
+// so the epilogue's dword loads and stores are whole 128-byte half rows of [pixel][channel] without any exchange between lanes.
 // Same interface, tensors and results as conv_split_kernel<256, 64, 8, 1, true> (bit-identical: same products, same k order
 // per output element: slice, tap, k-step, product).
 #include <atomic>
@@ -40,9 +42,7 @@ constexpr int C_NBUF = 3;
 constexpr int C_ZROW = C_NBUF * C_STAGE;  // 256 bytes of zeros
 constexpr int C_MASK = C_ZROW + 256;      // per-pixel-of-the-image 9-bit tap validity masks (u32), up to C_MAXHW pixels
 constexpr int C_MAXHW = 1024;
-constexpr int C_OSTAGE = C_MASK + C_MAXHW * 4;      // epilogue: a 32 pixel x 32 channel fp32 block per wave (4 KB each), to turn
-                                                     // "a lane owns a pixel" into "eight lanes own a pixel's 128 bytes"
-constexpr int C_LDS = C_OSTAGE + 4 * 4096 + 16;
+constexpr int C_LDS = C_MASK + C_MAXHW * 4 + 16;
 constexpr int C_PIECES = C_HROWS / 8;     // 40 one-KB pieces per slice patch
 constexpr int C_PW = C_PIECES / 4;        // 10 per wave
 constexpr unsigned C_OOB = 0xFFFFFF00u, C_HOOB = 0x80000000u;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, 1) void conv_c64r_kernel(ConvLaunch p, int n_t
   for (int j = 0; j < 4; ++j) lrow[j] = 32 * (2 * j + ph) + fr + wimg + 1;      // patch row of my pixel of block j, centre tap
 
 #define C64_PIN() __builtin_amdgcn_sched_barrier(0)
-#define C64_MFMA1(ACC, WCL, WV, PXV) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : WCL(WV), "v"(PXV))
+#define C64_MFMA1(ACC, WCL, WV, PXV) asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %1, %0" : "+v"(ACC) : WCL(WV), "v"(PXV))
   // one pixel block's three products of a k-step: weight planes W0 (first pieces), W1 (remainders); pixel pieces PX[0], PX[1]
   // (per block and k-step three products in this order: weights' first pieces x pixels' remainders, weights' remainders x pixels'
   // first pieces, first pieces x first pieces - small terms first, like conv_split.hip)
@@ -330,56 +330,44 @@ __global__ __launch_bounds__(256, 1) void conv_c64r_kernel(ConvLaunch p, int n_t
 
       if (slice == 1) {
         // ---- epilogue: 1 / (weight scale x activation scale) x accumulator + bias + residual, ReLU, store.
-        // In the accumulators a lane owns a pixel and 4 x 4 of its channels: a 16-byte access per lane then touches 32 different
-        // 256-byte pixel rows per instruction, and 16 of those per lane made the epilogue the longest phase of a tile (store
-        // issue, not bytes).  Each block goes through a wave-private 4 KB stage in LDS instead and comes back with eight lanes
-        // on one pixel's 128 contiguous bytes: the residual loads and the stores are whole cache lines.
+        // The pixels are the MFMAs' first operand: in the accumulators a lane owns ONE output channel (32 cb + fr) and sixteen pixels
+        // of the block (8 (r / 4) + 4 fh + r % 4), so that one dword access per accumulator register covers two whole 128-byte
+        // half rows ([pixel][32 cb .. 32 cb + 31]): residual loads and stores are full lines with no exchange between lanes.
         C64_DRAIN();
         const float floor_v = p.relu ? 0.f : -__builtin_huge_valf();
-        char* ost = smem + C_OSTAGE + wave * 4096;
-        const int tp = lane >> 3, tc = lane & 7;             // transposed role: pixel tp + 8 i of the block, channels 4 tc .. 4 tc + 3
-        const float4 bb = *reinterpret_cast<const float4*>(p.bias + 32 * cb + 4 * tc);
+        const float bb = p.bias[32 * cb + fr];
         // software pipeline over the four blocks: the residual of block j + 1 is requested BEFORE block j's stores (a load behind
         // a store waits for the store: one counter, in order), so a block's loads are never younger than a store they wait for
-        u32x4c rr[4], rn[4];
+        float rr[16], rn[16];
+#define C64_PIX(J, R) (tile * C_BM + 32 * (2 * (J) + ph) + 8 * ((R) >> 2) + 4 * fh + ((R) & 3))
 #define C64_RES(DST, J)                                                                              \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                              \
-          const int m_ = tile * C_BM + 32 * (2 * (J) + ph) + tp + 8 * i;                             \
-          DST[i] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, m_ < M ? (unsigned)(m_ * COUT + 32 * cb + 4 * tc) * 4u : C_OOB, 0, 0); \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
+          const int m_ = C64_PIX(J, r);                                                              \
+          DST[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_rsrc, m_ < M ? (unsigned)(m_ * COUT + 32 * cb + fr) * 4u : C_OOB, 0, 0)); \
         }
         C64_RES(rr, 0)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+          float o[16];
 #pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {                   // my pixel fr, channels 8 g4 + 4 fh ..: chunk 2 g4 + fh of row fr (swizzled)
-            float4 v;
-            v.x = acc[j][4 * g4 + 0]; v.y = acc[j][4 * g4 + 1]; v.z = acc[j][4 * g4 + 2]; v.w = acc[j][4 * g4 + 3];
-            *reinterpret_cast<float4*>(ost + fr * 128 + (((2 * g4 + fh) ^ (fr & 7)) << 4)) = v;
-          }
-          u32x4c pk[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int pr = tp + 8 * i;
-            const float4 a = *reinterpret_cast<const float4*>(ost + pr * 128 + ((tc ^ (pr & 7)) << 4));
-            const unsigned keep = tile * C_BM + 32 * (2 * j + ph) + pr < M ? 0x7FFFFFFFu : 0u;
-            pk[i].x = __float_as_uint(fmaxf(fmaf(a.x, tot_unscale, bb.x + __uint_as_float(rr[i].x)), floor_v));
-            pk[i].y = __float_as_uint(fmaxf(fmaf(a.y, tot_unscale, bb.y + __uint_as_float(rr[i].y)), floor_v));
-            pk[i].z = __float_as_uint(fmaxf(fmaf(a.z, tot_unscale, bb.z + __uint_as_float(rr[i].z)), floor_v));
-            pk[i].w = __float_as_uint(fmaxf(fmaf(a.w, tot_unscale, bb.w + __uint_as_float(rr[i].w)), floor_v));
-            out_bits = max(max(out_bits, max(pk[i].x & keep, pk[i].y & keep)), max(pk[i].z & keep, pk[i].w & keep));
+          for (int r = 0; r < 16; ++r) {
+            o[r] = fmaxf(fmaf(acc[j][r], tot_unscale, bb + rr[r]), floor_v);
+            const unsigned keep = C64_PIX(j, r) < M ? 0x7FFFFFFFu : 0u;
+            out_bits = max(out_bits, __float_as_uint(o[r]) & keep);
           }
           if (j < 3) {
             C64_RES(rn, j + 1)
           }
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int m = tile * C_BM + 32 * (2 * j + ph) + tp + 8 * i;
-            __builtin_amdgcn_raw_buffer_store_b128(pk[i], o_rsrc, m < M ? (unsigned)(m * COUT + 32 * cb + 4 * tc) * 4u : C_OOB, 0, 0);
+          for (int r = 0; r < 16; ++r) {
+            const int m = C64_PIX(j, r);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[r]), o_rsrc, m < M ? (unsigned)(m * COUT + 32 * cb + fr) * 4u : C_OOB, 0, 0);
           }
 #pragma unroll
-          for (int i = 0; i < 4; ++i) rr[i] = rn[i];
+          for (int r = 0; r < 16; ++r) rr[r] = rn[r];
         }
 #undef C64_RES
+#undef C64_PIX
       }
       C64_STAMP(3)
       if (run + 1 < n_runs) {
