@@ -431,10 +431,10 @@ class HipEngine:
         """Split-fp16 mode: layer1's BasicBlocks as one launch each (default) or as two convolution launches (A/B tests)."""
         self._check(self.lib.ut_set_block_fusion(self._h, int(bool(on))), "ut_set_block_fusion")
 
-    def set_resident_weights(self, on: bool):
-        """Split-fp16 mode: layer2's 64 -> 64 convolutions with the weights resident in registers (default) or through the chunked
-        kernel of the other layers (A/B tests; same bits)."""
-        self._check(self.lib.ut_set_resident_weights(self._h, int(bool(on))), "ut_set_resident_weights")
+    def set_resident_weights(self, kind=1):
+        """Split-fp16 mode: layer2's 64 -> 64 convolutions with the weights resident in registers: 1 / True the K-split pair kernel
+        (default), 2 the one-wave-per-SIMD kernel (the chunked kernel's bits), 0 / False the chunked kernel of the other layers."""
+        self._check(self.lib.ut_set_resident_weights(self._h, int(kind)), "ut_set_resident_weights")
 
     def set_latency_mode(self, on: bool):
         """Few-crop launches split K across workgroups (per-frame tracking); results then agree with the default mode to

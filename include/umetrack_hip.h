@@ -120,9 +120,11 @@ int ut_set_conv_arithmetic(ut_handle h, int mode);
  * so the two forms agree to the split arithmetic's rounding (~1e-7 relative), not bit for bit.  0 is for A/B tests. */
 int ut_set_block_fusion(ut_handle h, int on);
 
-/* Split-fp16 mode only: layer2's stride-1 64 -> 64 convolutions through the kernel that keeps the weights of an output block in
- * registers (csrc/conv_c64r.hip; 1 = default) or through the chunked kernel every other layer uses (0).  Same products in the
- * same order per output element: the two give the same bits; 0 is for A/B tests. */
+/* Split-fp16 mode only: layer2's stride-1 64 -> 64 convolutions with the weights of an output block resident in registers.
+ * 1 (default): csrc/conv_c64k.hip - two waves per SIMD share an output block and split its K; their partial sums are added
+ *    (slice 0) + (slice 1), so results agree with the chunked kernel's single running sum to fp32 rounding, not bit for bit.
+ * 2: csrc/conv_c64r.hip - one wave per SIMD, one running sum: the chunked kernel's bits.
+ * 0: the chunked kernel every other layer uses.  0 and 2 are for A/B tests. */
 int ut_set_resident_weights(ut_handle h, int on);
 
 /* Latency mode for calls on a handful of crops (the per-frame tracker): convolutions whose launch has far fewer tiles

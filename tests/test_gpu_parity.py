@@ -106,22 +106,30 @@ def test_split_f16_backbone_matches_oracle(engine, split_engine):
 
 
 @pytest.mark.parametrize("n_crops", [1, 5, 37, 300])
-def test_split_f16_resident_weight_kernel_gives_the_chunked_kernels_bits(split_engine, n_crops):
-    """conv_c64r.hip (layer2's five stride-1 64 -> 64 convolutions, weights resident in registers, one wave per SIMD) against
-    conv_split_kernel<256, 64, 8, 1, true> on the same tensors: the same products in the same order per output element, so the
-    backbone's features are equal bit for bit.  1 crop = 2.25 tiles (fewer tiles than workgroups, a ragged last tile, image
-    borders inside a tile), 5 crops = 11.25 tiles, 37 = 83.25, 300 crops = 675 tiles on 256 persistent workgroups (2.6 tiles each:
-    the three-buffer patch ring wraps, workgroups with two and with three tiles)."""
+def test_split_f16_resident_weight_kernels_against_the_chunked_kernel(engine, split_engine, n_crops):
+    """Layer2's five stride-1 64 -> 64 convolutions with the weights resident in registers against conv_split_kernel<256, 64, 8, 1,
+    true> on the same tensors.  conv_c64r.hip (one wave per SIMD, one running sum over K): the same products in the same order per
+    output element - the backbone's features are equal bit for bit.  conv_c64k.hip (the default: two waves per SIMD split K and add
+    their partial sums; bias and residual enter through one wave's accumulators): fp32 rounding apart, far inside the split
+    arithmetic's own distance to fp32, and deterministic.  1 crop = 4.5 tiles of 128 pixels (fewer tiles than workgroups, a ragged
+    last tile, image borders inside a tile), 5 crops = 22.5, 37 = 166.5, 300 crops = 1350 tiles on 256 persistent workgroups
+    (5.3 tiles each: the double-buffered patches wrap, workgroups with five and with six tiles)."""
     crops = _dev(synth.synthetic_crops(n_crops, seed=23 + n_crops))
-    resident = split_engine.backbone(crops)
-    split_engine.set_resident_weights(False)
+    pair = split_engine.backbone(crops)
     try:
+        split_engine.set_resident_weights(0)
         chunked = split_engine.backbone(crops)
+        split_engine.set_resident_weights(2)
+        single = split_engine.backbone(crops)
     finally:
-        split_engine.set_resident_weights(True)
-    assert torch.isfinite(resident).all()
-    assert torch.equal(resident, chunked)
-    assert torch.equal(split_engine.backbone(crops), resident)       # deterministic
+        split_engine.set_resident_weights(1)
+    assert torch.isfinite(pair).all()
+    assert torch.equal(single, chunked)
+    assert torch.equal(split_engine.backbone(crops), pair)           # deterministic
+    fp32 = engine.backbone(crops)
+    scale = max(1.0, fp32.abs().max().item())
+    assert (pair - chunked).abs().max().item() < 2e-6 * scale
+    assert (pair - fp32).abs().max().item() < 1e-5 * scale
 
 
 def test_split_f16_fused_layer1_blocks_match_the_two_launch_form(engine, split_engine):

@@ -41,7 +41,7 @@ variants = [v for v in os.environ.get("SPLIT_VARIANTS", "").split(",") if v]
 ALT_SRC = os.environ.get("SPLIT_ALT_SRC")
 
 
-def build(name, patches, flags=(), alt=None, c64=None):
+def build(name, patches, flags=(), alt=None, c64=None, c64k=None):
     src = alt or os.path.join(CSRC, "conv_split.hip")
     if patches:
         text = open(src).read()
@@ -53,13 +53,13 @@ def build(name, patches, flags=(), alt=None, c64=None):
     c64_src = c64 or os.path.join(CSRC, "conv_c64r.hip")
     so = f"/tmp/libsplitab_{name}.so"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w", *flags, "-o", so,
-                           os.path.join(CSRC, "conv_igemm.hip"), os.path.join(CSRC, "conv_patch.hip"), c64_src, src,
+                           os.path.join(CSRC, "conv_igemm.hip"), os.path.join(CSRC, "conv_patch.hip"), c64_src, c64k or os.path.join(CSRC, "conv_c64k.hip"), src,
                            os.path.join(ROOT, "tools", "diag", "split_entry.hip"), "-I", CSRC])
     return ctypes.CDLL(so)
 
 
-if os.environ.get("C64_STAMPS") == "1":      # phase stamps of conv_c64r.hip (third tile, second run of every workgroup)
-    lib = build("stamps", [], flags=["-DC64_STAMPS"])
+if os.environ.get("C64_STAMPS"):      # phase stamps of conv_c64k.hip (fourth tile of every workgroup; 1: the epilogue wave of a pair, 2: the other)
+    lib = build("stamps", [], flags=["-DC64_STAMPS=" + os.environ["C64_STAMPS"]] + (["-DK_ABL=" + os.environ["K_ABL"]] if os.environ.get("K_ABL") else []))
 else:
     lib = build("product", [])
 vlibs = {}
@@ -74,6 +74,9 @@ for v in variants:
 if ALT_SRC:
     vlibs["alt"] = build("alt", [], alt=ALT_SRC)
 # C64_ALT_SRCS=<path>,<path>: other versions of conv_c64r.hip (with the product conv_split.hip), timed beside the product as c64:<file>
+for path in [q for q in os.environ.get("C64K_ALT_SRCS", "").split(",") if q]:      # likewise for conv_c64k.hip
+    nm = os.path.splitext(os.path.basename(path))[0]
+    vlibs["c64k:" + nm] = build("c64k_" + nm, [], c64k=path)
 for path in [q for q in os.environ.get("C64_ALT_SRCS", "").split(",") if q]:
     nm = os.path.splitext(os.path.basename(path))[0]
     vlibs["c64:" + nm] = build("c64_" + nm, [], c64=path)
@@ -104,14 +107,14 @@ def run(mode, lib=lib):
     assert rc == 0, rc
 
 
-if os.environ.get("C64_STAMPS") == "1":
+if os.environ.get("C64_STAMPS"):
     run(1)
     buf = np.zeros(256 * 8, np.uint64)
     assert lib.conv_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
-    st = buf.reshape(256, 8)[:, :5].astype(np.int64)
+    st = buf.reshape(256, 8)[:, :6].astype(np.int64)
     d = np.diff(st, axis=1)
-    for i, nm in enumerate(["MFMA loop of the run (216 MFMAs)", "vmcnt wait (next patch landed)", "epilogue (residual, stores)", "B1 + split of the next patch + B2"]):
-        print(f"   {nm:40s} median {int(np.median(d[:, i])):7d}  p10 {int(np.percentile(d[:, i], 10)):7d}  p90 {int(np.percentile(d[:, i], 90)):7d}")
+    for i, nm in enumerate(["MFMA loop (108 MFMAs)", "vmcnt + barrier B1", "split of the next patches (+ partial sums out)", "barrier B2", "epilogue (epilogue wave only)"]):
+        print(f"   {nm:48s} median {int(np.median(d[:, i])):7d}  p10 {int(np.percentile(d[:, i], 10)):7d}  p90 {int(np.percentile(d[:, i], 90)):7d}")
     sys.exit(0)
 nref = min(n_img, 6)
 ref = torch.nn.functional.conv2d(x[:nref].permute(0, 3, 1, 2).double().cpu(), w_oihw.double(), bias[:cout].double(), stride, ksize // 2)
@@ -127,8 +130,17 @@ for mode, name in ((0, "fp32 mfma"), (1, "split f16x3")):
     print(f"{name:14s} max |out - f64 conv| over {nref} images = {float((o[:nref].double().cpu() - ref).abs().max()):.3e}")
 a, b = outs["fp32 mfma"], outs["split f16x3"]
 print(f"max |split - fp32| over all {n_img} images = {float((a - b).abs().max()):.3e}   (|out| max {float(a.abs().max()):.2f})")
+if cin == 64 and cout == 64 and ksize == 3 and stride == 1:
+    for mode, name in ((2, "c64r"), (3, "chunked")):
+        out.fill_(float("nan"))
+        run(mode)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all(), name
+        print(f"max |{name} - c64k| over all {n_img} images = {float((out - b).abs().max()):.3e}   max |{name} - f64| = {float((out[:nref].double().cpu() - ref).abs().max()):.3e}")
 flops = 2.0 * n_img * ho * ho * cout * k_total
 cases = [("fp32 mfma", 0, lib), ("split f16x3", 1, lib)] + [(v, 1, l) for v, l in vlibs.items()]
+if cin == 64 and cout == 64 and ksize == 3 and stride == 1:
+    cases += [("c64r (one wave/SIMD)", 2, lib), ("chunked 256x64 HALO", 3, lib)]
 times = {name: [] for name, _m, _l in cases}
 for rnd in range(10):
     for name, mode, l in cases:

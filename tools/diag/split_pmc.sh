@@ -15,7 +15,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace -d /tmp/spmc_$i -o run --output-format csv -- python3 $R/tools/diag/split_ab.py $1 $2 $3 $4 > $O/pass_$i.log 2>&1 || { echo "pass $i failed"; tail -5 $O/pass_$i.log; continue; }
   python3 - /tmp/spmc_$i/run_counter_collection.csv /tmp/spmc_$i/run_kernel_trace.csv <<'PY'
 import csv, sys, collections
-for pat in ("conv_c64r", "conv_split", "conv_igemm"):
+for pat in ("conv_c64k", "conv_c64r", "conv_split", "conv_igemm"):
     tr = [r for r in csv.DictReader(open(sys.argv[2])) if pat in r["Kernel_Name"]]
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
     if d:

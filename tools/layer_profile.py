@@ -45,7 +45,7 @@ head = [("fus0 144->108", 144 * 108), ("fus1 108->72", 108 * 72), ("fus2 72->72"
         ("reg1.conv1 76", 9 * 76 * 76), ("reg1.conv2 76", 9 * 76 * 76)]
 seq += [(nm, 2 * mac * 36 * s) for nm, mac in head]
 
-is_conv = lambda r: any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_c32_patch", "conv_split", "conv_block32", "conv_c64r"))
+is_conv = lambda r: any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_c32_patch", "conv_split", "conv_block32", "conv_c64r", "conv_c64k"))
 
 
 def label(name):
@@ -56,6 +56,8 @@ def label(name):
         return "fused block 12x16 split f16"
     if "conv_c64r" in name:
         return "split f16 256x64 reg weights"
+    if "conv_c64k" in name:
+        return "split f16 128x64 regW K-split"
     if "conv3x3_c32_patch" in name:
         return "halo patch 16x24" + (" split f16" if args == "true" else "")
     return "fp32 " + "x".join(args.split(", ")[:2])
