@@ -9,17 +9,21 @@
 // k-steps x 2 planes = 36 fragments = 144 registers, in the accumulator half of the file), wave ks = 1 those of channels 32..63.
 //   * a tile is 128 consecutive pixels (4 blocks of 32); the wave pair (cb, ph) owns output channels 32 cb .. 32 cb + 31 of the
 //     blocks 2 j + ph; each wave runs 9 taps x 2 k-steps x 2 blocks x 3 products = 108 MFMAs per tile on its slice of the patch
-//     with no synchronisation inside;
+//     with no synchronisation inside (the ninth tap's weights, which do not fit beside the other eight in the accumulator half
+//     of a 256-register wave, are read from LDS where they are used);
 //   * both 32-channel slices of a tile's input rows (128 + one image row and one pixel on either side: <= 192 rows) are in LDS
 //     at once, the next tile's two slices stream in meanwhile (4 x 24 KB; every wave transfers six 1-KB pieces of its own
-//     slice), then all 512 threads split them in place between two barriers;
-//   * wave ks = 1 hands its partial sums to its partner through LDS (8 KB per pair) and goes on to the next tile's MFMAs; wave
-//     ks = 0 adds them and runs the epilogue - so a SIMD's matrix pipe has the other wave's MFMAs while one wave is in its
-//     epilogue, and LDS / global latencies of one wave are covered by the other.
-// MFMAs are inline asm (operand classes are this file's choice, wait states in K_LEAD / K_DRAIN), the pixels are their first
-// operand (a lane's accumulators are one output channel of sixteen pixels: dword accesses of the epilogue are whole 128-byte
-// half rows).  Same interface and tensors as conv_split_kernel<256, 64, 8, 1, true>; the sum over K is taken as (slice 0) +
-// (slice 1) instead of one running sum: results agree with that kernel's to fp32 rounding, not bit for bit; deterministic.
+//     slice and counts them in when they have landed);
+//   * wave ks = 1 starts a tile from (residual + bias) / scale in its accumulators instead of zero, hands its partial sums to
+//     its partner through LDS (8 KB per pair), then splits BOTH slices of the next tile's patches in place and requests the next
+//     tile's residual; wave ks = 0 - which started the tile later - adds the partial sums, scales, clamps and stores (no load on
+//     its path) after the tile's ONE barrier, while its partner is in the next tile's MFMAs: a SIMD's matrix pipe has the other
+//     wave's MFMAs while one wave is in its epilogue or in the split, and LDS / global latencies of one wave are covered by the other.
+// MFMAs are inline asm (operand classes and registers are this file's choice; an asm MFMA's wait states travel inside the
+// statement where the compiler could put a copy next to it), the pixels are their first operand (a lane's accumulators are one
+// output channel of sixteen pixels: dword accesses of the epilogue are whole 128-byte half rows).  Same interface and tensors as
+// conv_split_kernel<256, 64, 8, 1, true>; the sum over K is taken as (slice 0) + (slice 1, residual, bias) instead of one running
+// sum with bias and residual added last: results agree with that kernel's to fp32 rounding, not bit for bit; deterministic.
 #include <atomic>
 
 #include "ut_kernels.h"
@@ -40,7 +44,8 @@ constexpr int K_MASK = K_ZROW + 256;      // per-pixel-of-the-image 9-bit tap va
 constexpr int K_MAXHW = 1024;
 constexpr int K_XCH = K_MASK + K_MAXHW * 4;          // partial sums of the ks = 1 waves: 4 pairs x 2 blocks x 4 KB
 constexpr int K_W8 = K_XCH + 4 * 2 * 4096;           // the ninth tap's weight fragments of (cb, ks): 4 x 4 KB
-constexpr int K_LDS = K_W8 + 4 * 4096 + 16;
+constexpr int K_CNT = K_W8 + 4 * 4096;               // three counters (monotonic): patches landed [slice 0], [slice 1]; exchange area read
+constexpr int K_LDS = K_CNT + 32;
 constexpr int K_PW = K_HROWS / 8 / 4;     // 1-KB pieces of a slice patch per wave of that slice: 6
 constexpr unsigned K_HOOB = 0x80000000u;
 static_assert(K_ZROW % 256 == 0, "zero block bank-row aligned");
@@ -68,6 +73,79 @@ __device__ __forceinline__ void k_split_scaled(float a, float b, float s, unsign
   p0 = __builtin_bit_cast(unsigned, h);
   p1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
 }
+
+// Accumulator-file registers of weight fragment f = tap * 4 + k-step * 2 + plane: a[4 f : 4 f + 3], as inline-asm constraints.  Every
+// use pins the fragment to the same physical registers, so the compiler knows they are occupied (registers it is not told about it
+// hands to other values) and has no reason to move them (with plain "a" constraints its allocator kept shuffling and spilling them).
+#define K_AR_0_0_0 "{a[0:3]}"
+#define K_AR_0_0_1 "{a[4:7]}"
+#define K_AR_0_1_0 "{a[8:11]}"
+#define K_AR_0_1_1 "{a[12:15]}"
+#define K_AR_1_0_0 "{a[16:19]}"
+#define K_AR_1_0_1 "{a[20:23]}"
+#define K_AR_1_1_0 "{a[24:27]}"
+#define K_AR_1_1_1 "{a[28:31]}"
+#define K_AR_2_0_0 "{a[32:35]}"
+#define K_AR_2_0_1 "{a[36:39]}"
+#define K_AR_2_1_0 "{a[40:43]}"
+#define K_AR_2_1_1 "{a[44:47]}"
+#define K_AR_3_0_0 "{a[48:51]}"
+#define K_AR_3_0_1 "{a[52:55]}"
+#define K_AR_3_1_0 "{a[56:59]}"
+#define K_AR_3_1_1 "{a[60:63]}"
+#define K_AR_4_0_0 "{a[64:67]}"
+#define K_AR_4_0_1 "{a[68:71]}"
+#define K_AR_4_1_0 "{a[72:75]}"
+#define K_AR_4_1_1 "{a[76:79]}"
+#define K_AR_5_0_0 "{a[80:83]}"
+#define K_AR_5_0_1 "{a[84:87]}"
+#define K_AR_5_1_0 "{a[88:91]}"
+#define K_AR_5_1_1 "{a[92:95]}"
+#define K_AR_6_0_0 "{a[96:99]}"
+#define K_AR_6_0_1 "{a[100:103]}"
+#define K_AR_6_1_0 "{a[104:107]}"
+#define K_AR_6_1_1 "{a[108:111]}"
+#define K_AR_7_0_0 "{a[112:115]}"
+#define K_AR_7_0_1 "{a[116:119]}"
+#define K_AR_7_1_0 "{a[120:123]}"
+#define K_AR_7_1_1 "{a[124:127]}"
+// (tap 8 is not register-resident: these only let the discarded branch of an `if constexpr` parse)
+#define K_AR_8_0_0 "v"
+#define K_AR_8_0_1 "v"
+#define K_AR_8_1_0 "v"
+#define K_AR_8_1_1 "v"
+#define K_ARF_0 "{a[0:3]}"
+#define K_ARF_1 "{a[4:7]}"
+#define K_ARF_2 "{a[8:11]}"
+#define K_ARF_3 "{a[12:15]}"
+#define K_ARF_4 "{a[16:19]}"
+#define K_ARF_5 "{a[20:23]}"
+#define K_ARF_6 "{a[24:27]}"
+#define K_ARF_7 "{a[28:31]}"
+#define K_ARF_8 "{a[32:35]}"
+#define K_ARF_9 "{a[36:39]}"
+#define K_ARF_10 "{a[40:43]}"
+#define K_ARF_11 "{a[44:47]}"
+#define K_ARF_12 "{a[48:51]}"
+#define K_ARF_13 "{a[52:55]}"
+#define K_ARF_14 "{a[56:59]}"
+#define K_ARF_15 "{a[60:63]}"
+#define K_ARF_16 "{a[64:67]}"
+#define K_ARF_17 "{a[68:71]}"
+#define K_ARF_18 "{a[72:75]}"
+#define K_ARF_19 "{a[76:79]}"
+#define K_ARF_20 "{a[80:83]}"
+#define K_ARF_21 "{a[84:87]}"
+#define K_ARF_22 "{a[88:91]}"
+#define K_ARF_23 "{a[92:95]}"
+#define K_ARF_24 "{a[96:99]}"
+#define K_ARF_25 "{a[100:103]}"
+#define K_ARF_26 "{a[104:107]}"
+#define K_ARF_27 "{a[108:111]}"
+#define K_ARF_28 "{a[112:115]}"
+#define K_ARF_29 "{a[116:119]}"
+#define K_ARF_30 "{a[120:123]}"
+#define K_ARF_31 "{a[124:127]}"
 
 }  // namespace
 
@@ -105,17 +183,55 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
 
   // ---- my weights: group cb of ConvLaunch::w_split ([cout / 32][chunk 18][k-step 2][plane 2][lane 64][8 halves]; chunk = slice * 9 +
   // tap), the nine chunks of slice ks: fragment f = tap * 4 + k-step * 2 + plane.  Taps 0..7 live in the accumulator half of the
-  // register file, in registers this file names itself (a[4 f : 4 f + 3]: the compiler is told they are in use and touches none
-  // of them - its allocator, given 32 four-register values to keep there, kept shuffling and spilling them); the ninth tap's four
-  // fragments are read from LDS where they are used (4 KB per tile and wave).
+  // register file, each pinned to its own registers a[4 f : 4 f + 3] at every use (K_AR_* above); the ninth tap's four fragments
+  // are read from LDS where they are used (4 KB per tile and wave).
+  u32x4k wa[32];
   {
     const char* wg = reinterpret_cast<const char*>(p.w_split) + ((size_t)cb * 18 + (size_t)ks * 9) * 4096 + lane * 16;
-#define K_WLOAD(F) asm volatile("global_load_dwordx4 a[%1:%2], %0, off offset:%3" ::"v"(wg + ((F) / 4) * 4096), "n"(4 * (F)), "n"(4 * (F) + 3), "n"(((F) % 4) * 1024) : "memory");
-#define K_WLOAD4(F) K_WLOAD(F) K_WLOAD((F) + 1) K_WLOAD((F) + 2) K_WLOAD((F) + 3)
-    K_WLOAD4(0) K_WLOAD4(4) K_WLOAD4(8) K_WLOAD4(12) K_WLOAD4(16) K_WLOAD4(20) K_WLOAD4(24) K_WLOAD4(28)
-#undef K_WLOAD4
-#undef K_WLOAD
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory", "a127");      // (the clobber makes a0..a127 part of the kernel's register count)
+    // (sixteen requests and their wait in ONE statement: the compiler takes an asm's outputs as ready where the statement ends, and
+    // would spill or copy a register whose load has not landed)
+    asm volatile(
+        "global_load_dwordx4 %0, %16, off offset:0\n\t"
+        "global_load_dwordx4 %1, %16, off offset:1024\n\t"
+        "global_load_dwordx4 %2, %16, off offset:2048\n\t"
+        "global_load_dwordx4 %3, %16, off offset:3072\n\t"
+        "global_load_dwordx4 %4, %17, off offset:0\n\t"
+        "global_load_dwordx4 %5, %17, off offset:1024\n\t"
+        "global_load_dwordx4 %6, %17, off offset:2048\n\t"
+        "global_load_dwordx4 %7, %17, off offset:3072\n\t"
+        "global_load_dwordx4 %8, %18, off offset:0\n\t"
+        "global_load_dwordx4 %9, %18, off offset:1024\n\t"
+        "global_load_dwordx4 %10, %18, off offset:2048\n\t"
+        "global_load_dwordx4 %11, %18, off offset:3072\n\t"
+        "global_load_dwordx4 %12, %19, off offset:0\n\t"
+        "global_load_dwordx4 %13, %19, off offset:1024\n\t"
+        "global_load_dwordx4 %14, %19, off offset:2048\n\t"
+        "global_load_dwordx4 %15, %19, off offset:3072\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&" K_ARF_0(wa[0]), "=&" K_ARF_1(wa[1]), "=&" K_ARF_2(wa[2]), "=&" K_ARF_3(wa[3]), "=&" K_ARF_4(wa[4]), "=&" K_ARF_5(wa[5]), "=&" K_ARF_6(wa[6]), "=&" K_ARF_7(wa[7]), "=&" K_ARF_8(wa[8]), "=&" K_ARF_9(wa[9]), "=&" K_ARF_10(wa[10]), "=&" K_ARF_11(wa[11]), "=&" K_ARF_12(wa[12]), "=&" K_ARF_13(wa[13]), "=&" K_ARF_14(wa[14]), "=&" K_ARF_15(wa[15])
+        : "v"(wg + 0 * 4096), "v"(wg + 1 * 4096), "v"(wg + 2 * 4096), "v"(wg + 3 * 4096)
+        : "memory");
+    asm volatile(
+        "global_load_dwordx4 %0, %16, off offset:0\n\t"
+        "global_load_dwordx4 %1, %16, off offset:1024\n\t"
+        "global_load_dwordx4 %2, %16, off offset:2048\n\t"
+        "global_load_dwordx4 %3, %16, off offset:3072\n\t"
+        "global_load_dwordx4 %4, %17, off offset:0\n\t"
+        "global_load_dwordx4 %5, %17, off offset:1024\n\t"
+        "global_load_dwordx4 %6, %17, off offset:2048\n\t"
+        "global_load_dwordx4 %7, %17, off offset:3072\n\t"
+        "global_load_dwordx4 %8, %18, off offset:0\n\t"
+        "global_load_dwordx4 %9, %18, off offset:1024\n\t"
+        "global_load_dwordx4 %10, %18, off offset:2048\n\t"
+        "global_load_dwordx4 %11, %18, off offset:3072\n\t"
+        "global_load_dwordx4 %12, %19, off offset:0\n\t"
+        "global_load_dwordx4 %13, %19, off offset:1024\n\t"
+        "global_load_dwordx4 %14, %19, off offset:2048\n\t"
+        "global_load_dwordx4 %15, %19, off offset:3072\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&" K_ARF_16(wa[16]), "=&" K_ARF_17(wa[17]), "=&" K_ARF_18(wa[18]), "=&" K_ARF_19(wa[19]), "=&" K_ARF_20(wa[20]), "=&" K_ARF_21(wa[21]), "=&" K_ARF_22(wa[22]), "=&" K_ARF_23(wa[23]), "=&" K_ARF_24(wa[24]), "=&" K_ARF_25(wa[25]), "=&" K_ARF_26(wa[26]), "=&" K_ARF_27(wa[27]), "=&" K_ARF_28(wa[28]), "=&" K_ARF_29(wa[29]), "=&" K_ARF_30(wa[30]), "=&" K_ARF_31(wa[31])
+        : "v"(wg + 4 * 4096), "v"(wg + 5 * 4096), "v"(wg + 6 * 4096), "v"(wg + 7 * 4096)
+        : "memory");
     if (ph == 0) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -127,6 +243,7 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
 
   // ---- zero block, tap-validity masks of every pixel position of an image
   if (tid < 16) *reinterpret_cast<u32x4k*>(smem + K_ZROW + tid * 16) = u32x4k{0, 0, 0, 0};
+  if (tid == 16) *reinterpret_cast<u32x4k*>(smem + K_CNT) = u32x4k{0, 0, 0, 0};
   for (int pos = tid; pos < hw; pos += 512) {
     const int y = pos / wimg, x = pos - y * wimg;
     unsigned mk = 0;
@@ -153,35 +270,38 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
     k_dma(a_words, (unsigned)__builtin_amdgcn_readfirstlane((int)(smem_addr + (unsigned)(buf * K_STAGE + q * 1024))), off,
           (unsigned)ks * 128u);
   };
-  auto convert_patches = [&](int parity) {  // split both landed fp32 slice patches of a tile in place (group q = k / 8 at q ^ swizzle)
+  // split landed fp32 slice patches of a tile in place (group q = k / 8 at q ^ swizzle); unit u = slice * 192 + row, u < 384
+  auto convert_unit = [&](int parity, int u) {
+    const int sl = u >= K_HROWS ? 1 : 0, row = u - sl * K_HROWS;
+    const int sw = (row >> 1) & 7;
+    char* rp = smem + (parity * 2 + sl) * K_STAGE + row * 128;
+    float4 f[8];
+#pragma unroll
+    for (int g4 = 0; g4 < 8; ++g4) f[g4] = *reinterpret_cast<const float4*>(rp + ((g4 ^ sw) << 4));
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      unsigned a0, a1, a2, a3, b0, b1, b2, b3;
+      k_split_scaled(f[2 * kg].x, f[2 * kg].y, x_scale, a0, b0);
+      k_split_scaled(f[2 * kg].z, f[2 * kg].w, x_scale, a1, b1);
+      k_split_scaled(f[2 * kg + 1].x, f[2 * kg + 1].y, x_scale, a2, b2);
+      k_split_scaled(f[2 * kg + 1].z, f[2 * kg + 1].w, x_scale, a3, b3);
+      u32x4k a, b;
+      a.x = a0; a.y = a1; a.z = a2; a.w = a3;
+      b.x = b0; b.y = b1; b.z = b2; b.w = b3;
+      *reinterpret_cast<u32x4k*>(rp + ((kg ^ sw) << 4)) = a;
+      *reinterpret_cast<u32x4k*>(rp + (((4 + kg) ^ sw) << 4)) = b;
+    }
+  };
+  auto convert_patches = [&](int parity) {  // every thread of the workgroup (prologue)
     int t_ = tid;
     asm volatile("" : "+v"(t_));      // (opaque: the row's addresses are computed here, not kept in registers across the MFMA loop)
-    if (t_ < 2 * K_HROWS) {
-      const int sl = t_ >= K_HROWS ? 1 : 0, row = t_ - sl * K_HROWS;
-      const int sw = (row >> 1) & 7;
-      char* rp = smem + (parity * 2 + sl) * K_STAGE + row * 128;
-      float4 f[8];
-#pragma unroll
-      for (int g4 = 0; g4 < 8; ++g4) f[g4] = *reinterpret_cast<const float4*>(rp + ((g4 ^ sw) << 4));
-#pragma unroll
-      for (int kg = 0; kg < 4; ++kg) {
-        unsigned a0, a1, a2, a3, b0, b1, b2, b3;
-#if defined(K_ABL) && K_ABL == 2
-        a0 = __float_as_uint(f[2 * kg].x); b0 = __float_as_uint(f[2 * kg].y); a1 = __float_as_uint(f[2 * kg].z); b1 = __float_as_uint(f[2 * kg].w);
-        a2 = __float_as_uint(f[2 * kg + 1].x); b2 = __float_as_uint(f[2 * kg + 1].y); a3 = __float_as_uint(f[2 * kg + 1].z); b3 = __float_as_uint(f[2 * kg + 1].w);
-#else
-        k_split_scaled(f[2 * kg].x, f[2 * kg].y, x_scale, a0, b0);
-        k_split_scaled(f[2 * kg].z, f[2 * kg].w, x_scale, a1, b1);
-        k_split_scaled(f[2 * kg + 1].x, f[2 * kg + 1].y, x_scale, a2, b2);
-        k_split_scaled(f[2 * kg + 1].z, f[2 * kg + 1].w, x_scale, a3, b3);
-#endif
-        u32x4k a, b;
-        a.x = a0; a.y = a1; a.z = a2; a.w = a3;
-        b.x = b0; b.y = b1; b.z = b2; b.w = b3;
-        *reinterpret_cast<u32x4k*>(rp + ((kg ^ sw) << 4)) = a;
-        *reinterpret_cast<u32x4k*>(rp + (((4 + kg) ^ sw) << 4)) = b;
-      }
-    }
+    if (t_ < 2 * K_HROWS) convert_unit(parity, t_);
+  };
+  auto convert_patches_ks1 = [&](int parity) {  // the four ks = 1 waves (256 threads, 384 units)
+    int t_ = tid - 256;
+    asm volatile("" : "+v"(t_));
+    convert_unit(parity, t_);
+    if (t_ < 2 * K_HROWS - 256) convert_unit(parity, t_ + 256);
   };
 
   // prologue: my first tile's patches, split
@@ -196,6 +316,7 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
   unsigned out_bits = 0;
   const float bias_v = p.bias[32 * cb + fr];      // my output channel's bias
   const float inv_unscale = 1.f / tot_unscale;    // (a power of two: exact)
+  const float bias_scaled = bias_v * inv_unscale;
   // Bias and residual enter through the ks = 1 wave's ACCUMULATORS: it starts a tile from (residual + bias) x inv_unscale instead
   // of zero (requested after barrier B1 of the tile before, landed under the split of the patches), so the epilogue wave has no
   // global load on its path - it adds the two partial sums, scales, clamps and stores.
@@ -217,14 +338,29 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
   int lrow[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) lrow[j] = 32 * (2 * j + ph) + fr + wimg + 1;      // patch row of my pixel of block j, centre tap
-  const unsigned xch = (unsigned)(K_XCH + grp * 8192 + lane * 16);               // the pair's exchange area, my 16 bytes of a KB
+  const unsigned xch = (unsigned)(K_XCH + grp * 8192 + lane * 16);
+  const unsigned cnt_addr = smem_addr + (unsigned)K_CNT;      // + 0 / + 4: patches of slice 0 / 1 landed; + 8: exchange area read               // the pair's exchange area, my 16 bytes of a KB
 
 #define K_PIN() __builtin_amdgcn_sched_barrier(0)
-#define K_MFMA_A(ACC, F, PXV) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%2:%3], %0" : "+v"(ACC) : "v"(PXV), "n"(4 * (F)), "n"(4 * (F) + 3))
+  // LDS counters between the waves of the workgroup (one lane adds; a waiter polls until the count is reached)
+#define K_SIGNAL(ADDR)                                                                               \
+  {                                                                                                  \
+    unsigned long long keep_;                                                                        \
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0" \
+                 : "=&s"(keep_) : "v"(ADDR), "v"(1u) : "memory");                                    \
+  }
+#define K_AWAIT(ADDR, TARGET)                                                                        \
+  for (;;) {                                                                                         \
+    unsigned seen_;                                                                                  \
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen_) : "v"(ADDR) : "memory"); \
+    if ((int)(__builtin_amdgcn_readfirstlane(seen_) - (unsigned)(TARGET)) >= 0) break;               \
+    __builtin_amdgcn_s_sleep(1);                                                                     \
+  }
+#define K_MFMA_A(ACC, TAP, S, PL, PXV) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(PXV), K_AR_##TAP##_##S##_##PL(wa[K_W(TAP, S, PL)]))
 #define K_MFMA_V(ACC, WV, PXV) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(PXV), "v"(WV))
   // (the compiler knows nothing of an asm MFMA's latency and may put a register copy of the accumulator right behind - or in front of -
   // it: the wait states travel INSIDE the statement of a block's first and last MFMA of a tile)
-#define K_MFMA_A_FIRST(ACC, F, PXV) asm volatile("s_nop 3\n\tv_mfma_f32_32x32x16_f16 %0, %1, a[%2:%3], %0" : "+v"(ACC) : "v"(PXV), "n"(4 * (F)), "n"(4 * (F) + 3))
+#define K_MFMA_A_FIRST(ACC, TAP, S, PL, PXV) asm volatile("s_nop 3\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(PXV), K_AR_##TAP##_##S##_##PL(wa[K_W(TAP, S, PL)]))
 #define K_MFMA_V_LAST(ACC, WV, PXV) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 7" : "+v"(ACC) : "v"(PXV), "v"(WV))
   // Address of the lane's 16 bytes of block J, tap TAP, k-step 0, first pieces, in the patch at byte offset BUF - or in the block of
   // zeros, on the same banks, when the tap leaves the image.  k-step 1 is that address ^ 32, the remainder pieces ^ 64.
@@ -241,43 +377,59 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
   }
 #define K_LEAD() asm volatile("s_nop 3")
 #define K_DRAIN() asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]))
-#define K_W(TAP, S, PL) ((TAP) * 4 + (S) * 2 + (PL))
+#define K_W(TAP, S, PL) (((TAP) * 4 + (S) * 2 + (PL)) & 31)
   // One k-step: for each of my two pixel blocks three MFMAs (weights' first pieces x pixels' remainders, weights' remainders x
-  // pixels' first pieces, first x first - small terms first, like conv_split.hip), with the work for the NEXT k-step of that block
-  // between them: the address of the next tap behind the first MFMA (S = 1 only: the next k-step is then a new tap), the two
-  // fragment reads behind the second, a transfer piece of the next tile's patch behind the third (block 1 only).
-#define K_STEP(TAP, S, CUR, NXT, HAVE_NEXT, PIECE)                                                   \
+  // pixels' first pieces, first x first - small terms first, like conv_split.hip).  The other instructions sit between them: the
+  // four fragment reads of the NEXT k-step right behind the step's first two MFMAs (five and seven MFMAs of this wave - twice that
+  // in time, with the SIMD's other wave interleaved - before their first use: a wave has only six MFMAs per k-step to cover an LDS
+  // round trip with), the addresses of the next tap's fragments one k-step before those reads (S = 0; address sets alternate by tap
+  // parity), a transfer piece of the next tile's patch behind the last one.
+  // MFMA W (0, 1, 2) of block J in k-step (TAP, S)
+#define K_MM(TAP, S, CUR, J, W)                                                                      \
+  {                                                                                                  \
+    if constexpr ((TAP) < 8) {                                                                       \
+      if constexpr ((W) == 0) {                                                                      \
+        if constexpr ((TAP) == 0 && (S) == 0) { K_MFMA_A_FIRST(acc[J], TAP, S, 0, CUR[J][1]); }      \
+        else { K_MFMA_A(acc[J], TAP, S, 0, CUR[J][1]); }                                             \
+      } else if constexpr ((W) == 1) { K_MFMA_A(acc[J], TAP, S, 1, CUR[J][0]); }                     \
+      else { K_MFMA_A(acc[J], TAP, S, 0, CUR[J][0]); }                                               \
+    } else {                                                                                         \
+      if constexpr ((W) == 0) { K_MFMA_V(acc[J], w8a_, CUR[J][1]); }                                 \
+      else if constexpr ((W) == 1) { K_MFMA_V(acc[J], w8b_, CUR[J][0]); }                            \
+      else if constexpr ((S) == 1) { K_MFMA_V_LAST(acc[J], w8a_, CUR[J][0]); }                       \
+      else { K_MFMA_V(acc[J], w8a_, CUR[J][0]); }                                                    \
+    }                                                                                                \
+    K_PIN();                                                                                         \
+  }
+#define K_STEP(TAP, S, CUR, NXT, HAVE_NEXT, PIECE, ADC, ADN)                                         \
   {                                                                                                  \
     u32x4k w8a_, w8b_;                                                                               \
     if constexpr ((TAP) == 8) {                                                                      \
       w8a_ = *reinterpret_cast<const u32x4k*>(smem + w8 + ((S) * 2 + 0) * 1024);                     \
       w8b_ = *reinterpret_cast<const u32x4k*>(smem + w8 + ((S) * 2 + 1) * 1024);                     \
     }                                                                                                \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                  \
-      if constexpr ((TAP) < 8) {                                                                     \
-        if constexpr ((TAP) == 0 && (S) == 0) { K_MFMA_A_FIRST(acc[j], K_W(TAP, S, 0), CUR[j][1]); } \
-        else { K_MFMA_A(acc[j], K_W(TAP, S, 0), CUR[j][1]); }                                        \
-        K_PIN();                                                                                     \
-        if constexpr (HAVE_NEXT && (S) == 1) K_ADDR(adr[j], rbuf, j, (TAP) + 1);                     \
-        K_PIN();                                                                                     \
-        K_MFMA_A(acc[j], K_W(TAP, S, 1), CUR[j][0]); K_PIN();                                        \
-        if constexpr (HAVE_NEXT) K_LOAD(NXT[j], adr[j], 1 - (S));                                    \
-        K_PIN();                                                                                     \
-        K_MFMA_A(acc[j], K_W(TAP, S, 0), CUR[j][0]); K_PIN();                                        \
-      } else {                                                                                       \
-        K_MFMA_V(acc[j], w8a_, CUR[j][1]); K_PIN();                                                  \
-        if constexpr (HAVE_NEXT && (S) == 1) K_ADDR(adr[j], rbuf, j, (TAP) + 1);                     \
-        K_PIN();                                                                                     \
-        K_MFMA_V(acc[j], w8b_, CUR[j][0]); K_PIN();                                                  \
-        if constexpr (HAVE_NEXT) K_LOAD(NXT[j], adr[j], 1 - (S));                                    \
-        K_PIN();                                                                                     \
-        if constexpr ((S) == 1) { K_MFMA_V_LAST(acc[j], w8a_, CUR[j][0]); }                          \
-        else { K_MFMA_V(acc[j], w8a_, CUR[j][0]); }                                                  \
-        K_PIN();                                                                                     \
-      }                                                                                              \
-      if (j == 1 && (PIECE) < K_PW && dma_on) issue_patch_piece(PIECE, f_tile, f_buf);               \
-      K_PIN();                                                                                       \
+    K_MM(TAP, S, CUR, 0, 0)                                                                          \
+    if constexpr (HAVE_NEXT && (S) == 0) K_LOAD(NXT[0], ADC[0], 1);                                  \
+    if constexpr (HAVE_NEXT && (S) == 1) K_LOAD(NXT[0], ADN[0], 0);                                  \
+    K_PIN();                                                                                         \
+    K_MM(TAP, S, CUR, 0, 1)                                                                          \
+    if constexpr (HAVE_NEXT && (S) == 0) K_LOAD(NXT[1], ADC[1], 1);                                  \
+    if constexpr (HAVE_NEXT && (S) == 1) K_LOAD(NXT[1], ADN[1], 0);                                  \
+    K_PIN();                                                                                         \
+    K_MM(TAP, S, CUR, 0, 2)                                                                          \
+    K_MM(TAP, S, CUR, 1, 0)                                                                          \
+    if constexpr ((S) == 0 && (TAP) < 8) K_ADDR(ADN[0], rbuf, 0, (TAP) + 1);                         \
+    K_PIN();                                                                                         \
+    K_MM(TAP, S, CUR, 1, 1)                                                                          \
+    if constexpr ((S) == 0 && (TAP) < 8) K_ADDR(ADN[1], rbuf, 1, (TAP) + 1);                         \
+    K_PIN();                                                                                         \
+    K_MM(TAP, S, CUR, 1, 2)                                                                          \
+    if ((PIECE) < K_PW && dma_on) issue_patch_piece(PIECE, f_tile, f_buf);                           \
+    if ((PIECE) == 77 && dma_on) {      /* my six pieces (issued 8+ k-steps ago) have landed: tell the splitting waves */ \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
+      K_SIGNAL(cnt_addr + 4u * (unsigned)ks);                                                        \
     }                                                                                                \
+    K_PIN();                                                                                         \
   }
 
 #ifdef C64_STAMPS      /* tools/diag only: phase stamps of my fourth tile (wave C64_STAMPS - 1 of the pair writes), to p.status */
@@ -316,7 +468,7 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][e] = (acc[j][e] + bias_v) * inv_unscale;
+        for (int e = 0; e < 16; ++e) acc[j][e] = __builtin_fmaf(acc[j][e], inv_unscale, bias_scaled);
     } else {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -329,48 +481,54 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
     K_STAMP(0)
     {
       u32x4k pxA[2][2], pxB[2][2];
-      unsigned adr[2];
+      unsigned adE[2], adO[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) { K_ADDR(adr[j], rbuf, j, 0); K_LOAD(pxA[j], adr[j], 0); }
+      for (int j = 0; j < 2; ++j) { K_ADDR(adE[j], rbuf, j, 0); K_LOAD(pxA[j], adE[j], 0); }
       K_LEAD();
-      K_STEP(0, 0, pxA, pxB, true, 0)  K_STEP(0, 1, pxB, pxA, true, 1)
-      K_STEP(1, 0, pxA, pxB, true, 2)  K_STEP(1, 1, pxB, pxA, true, 3)
-      K_STEP(2, 0, pxA, pxB, true, 4)  K_STEP(2, 1, pxB, pxA, true, 5)
-      K_STEP(3, 0, pxA, pxB, true, 99) K_STEP(3, 1, pxB, pxA, true, 99)
-      K_STEP(4, 0, pxA, pxB, true, 99) K_STEP(4, 1, pxB, pxA, true, 99)
-      K_STEP(5, 0, pxA, pxB, true, 99) K_STEP(5, 1, pxB, pxA, true, 99)
-      K_STEP(6, 0, pxA, pxB, true, 99) K_STEP(6, 1, pxB, pxA, true, 99)
-      K_STEP(7, 0, pxA, pxB, true, 99) K_STEP(7, 1, pxB, pxA, true, 99)
-      K_STEP(8, 0, pxA, pxB, true, 99) K_STEP(8, 1, pxB, pxA, false, 99)
+      K_STEP(0, 0, pxA, pxB, true, 0, adE, adO)  K_STEP(0, 1, pxB, pxA, true, 1, adE, adO)
+      K_STEP(1, 0, pxA, pxB, true, 2, adO, adE)  K_STEP(1, 1, pxB, pxA, true, 3, adO, adE)
+      K_STEP(2, 0, pxA, pxB, true, 4, adE, adO)  K_STEP(2, 1, pxB, pxA, true, 5, adE, adO)
+      K_STEP(3, 0, pxA, pxB, true, 99, adO, adE) K_STEP(3, 1, pxB, pxA, true, 99, adO, adE)
+      K_STEP(4, 0, pxA, pxB, true, 99, adE, adO) K_STEP(4, 1, pxB, pxA, true, 99, adE, adO)
+      K_STEP(5, 0, pxA, pxB, true, 99, adO, adE) K_STEP(5, 1, pxB, pxA, true, 99, adO, adE)
+      K_STEP(6, 0, pxA, pxB, true, 99, adE, adO) K_STEP(6, 1, pxB, pxA, true, 99, adE, adO)
+      K_STEP(7, 0, pxA, pxB, true, 77, adO, adE) K_STEP(7, 1, pxB, pxA, true, 99, adO, adE)
+      K_STEP(8, 0, pxA, pxB, true, 99, adE, adO) K_STEP(8, 1, pxB, pxA, false, 99, adE, adO)
     }
     K_DRAIN();
     K_STAMP(1)
+#ifdef C64_STAMPS
+    if (k == 3) { st_[2] = st_[1]; st_[3] = st_[1]; }
+#endif
 
-    // B1: every wave's pieces of the next tile's patches have landed, every wave's reads of this tile's patches are done
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    K_STAMP(2)
-    if (ks == 1) {               // my partial sums to my partner: block j at 4 KB j, accumulator registers 4 q .. 4 q + 3 at 1 KB q
+    // The ks = 1 waves hand over their partial sums, request the next tile's residual into the freed accumulators, and split BOTH
+    // slices of the next tile's patches (landed: counters) while the ks = 0 waves - which started this tile behind the last one's
+    // epilogue - finish their MFMAs.  ONE barrier per tile: every wave's reads of this tile's patches are done, the next tile's
+    // patches are split, the partial sums are in place.
+    if (ks == 1) {
+      K_AWAIT(cnt_addr + 8u, 4 * k)       // every epilogue wave has read the exchange area of the tile before
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)        // block j at 4 KB j, accumulator registers 4 q .. 4 q + 3 at 1 KB q
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float4 v;
           v.x = acc[j][4 * q + 0]; v.y = acc[j][4 * q + 1]; v.z = acc[j][4 * q + 2]; v.w = acc[j][4 * q + 3];
           *reinterpret_cast<float4*>(smem + xch + j * 4096 + q * 1024) = v;
         }
-      if (dma_on) {              // the accumulators are free: the next tile's residual lands in them under the split below
-        K_RINI(f_tile)
+      if (dma_on) {
+        K_STAMP(2)
+        K_AWAIT(cnt_addr, 4 * (k + 1))
+        K_AWAIT(cnt_addr + 4u, 4 * (k + 1))
+        K_STAMP(3)
+#if !defined(K_ABL) || K_ABL != 1
+        convert_patches_ks1((k + 1) & 1);
+#endif
+        K_RINI(f_tile)      // (behind the split: the accumulators are free registers for it; the requests land while I wait at the barrier)
       }
     }
-#if !defined(K_ABL) || K_ABL != 1
-    if (dma_on) convert_patches((k + 1) & 1);
-#endif
-    // B2: the next tile's patches are split, the partial sums are in place
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    K_STAMP(3)
-    __builtin_amdgcn_s_barrier();
     K_STAMP(4)
+    __builtin_amdgcn_s_barrier();
 
     if (ks == 0) {
       // ---- epilogue: 1 / (weight scale x activation scale) x (my sum + my partner's, which started from residual + bias), ReLU,
@@ -405,7 +563,8 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
 #pragma unroll
         for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[r]), o_rsrc, K_ROFF(off_j, r), 0, 0);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my reads of the exchange area are done before I reach the next B1
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my reads of the exchange area are done: my partner may write the next tile's
+      K_SIGNAL(cnt_addr + 8u);
     }
 #ifdef C64_STAMPS
     K_STAMP(5)
@@ -418,6 +577,8 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (p.out_max) publish_abs_max(p.out_max, out_bits);
 #undef K_PIN
+#undef K_SIGNAL
+#undef K_AWAIT
 #undef K_MFMA_A
 #undef K_MFMA_V
 #undef K_MFMA_A_FIRST
@@ -428,6 +589,7 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
 #undef K_DRAIN
 #undef K_W
 #undef K_STEP
+#undef K_MM
 #undef K_STAMP
 #undef K_OFF
 #undef K_ROFF

@@ -61,7 +61,7 @@ def build(name, patches, flags=(), alt=None, c64=None, c64k=None):
 if os.environ.get("C64_STAMPS"):      # phase stamps of conv_c64k.hip (fourth tile of every workgroup; 1: the epilogue wave of a pair, 2: the other)
     lib = build("stamps", [], flags=["-DC64_STAMPS=" + os.environ["C64_STAMPS"]] + (["-DK_ABL=" + os.environ["K_ABL"]] if os.environ.get("K_ABL") else []))
 else:
-    lib = build("product", [])
+    lib = build("product", [], c64k=os.environ.get("C64K_MAIN_SRC"))      # C64K_MAIN_SRC=<path>: another conv_c64k.hip as the main build
 vlibs = {}
 for v in variants:
     patches, flags = [], []
@@ -113,7 +113,7 @@ if os.environ.get("C64_STAMPS"):
     assert lib.conv_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
     st = buf.reshape(256, 8)[:, :6].astype(np.int64)
     d = np.diff(st, axis=1)
-    for i, nm in enumerate(["MFMA loop (108 MFMAs)", "vmcnt + barrier B1", "split of the next patches (+ partial sums out)", "barrier B2", "epilogue (epilogue wave only)"]):
+    for i, nm in enumerate(["MFMA loop (108 MFMAs)", "partial sums out, residual requests (ks = 1)", "wait: next patches landed (ks = 1)", "split of the next patches (ks = 1)", "barrier (+ epilogue: ks = 0)"]):
         print(f"   {nm:48s} median {int(np.median(d[:, i])):7d}  p10 {int(np.percentile(d[:, i], 10)):7d}  p90 {int(np.percentile(d[:, i], 90)):7d}")
     sys.exit(0)
 nref = min(n_img, 6)
@@ -126,7 +126,7 @@ for mode, name in ((0, "fp32 mfma"), (1, "split f16x3")):
     torch.cuda.synchronize()
     o = out.clone()
     outs[name] = o
-    assert torch.isfinite(o).all(), name
+    assert os.environ.get("ERRMAP") or torch.isfinite(o).all(), name
     print(f"{name:14s} max |out - f64 conv| over {nref} images = {float((o[:nref].double().cpu() - ref).abs().max()):.3e}")
 a, b = outs["fp32 mfma"], outs["split f16x3"]
 print(f"max |split - fp32| over all {n_img} images = {float((a - b).abs().max()):.3e}   (|out| max {float(a.abs().max()):.2f})")
