@@ -15,9 +15,9 @@
 //     at once, the next tile's two slices stream in meanwhile (4 x 24 KB; every wave transfers six 1-KB pieces of its own
 //     slice and counts them in when they have landed);
 //   * wave ks = 1 starts a tile from (residual + bias) / scale in its accumulators instead of zero, hands its partial sums to
-//     its partner through LDS (8 KB per pair), then splits BOTH slices of the next tile's patches in place and requests the next
-//     tile's residual; wave ks = 0 - which started the tile later - adds the partial sums, scales, clamps and stores (no load on
-//     its path) after the tile's ONE barrier, while its partner is in the next tile's MFMAs: a SIMD's matrix pipe has the other
+//     its partner through LDS (8 KB per pair) and requests the next tile's residual; behind its MFMAs every wave splits its own
+//     slice of the next tile's patches in place; wave ks = 0 adds the partial sums, scales, clamps and stores (no load on its
+//     path) after the tile's ONE barrier, while its partner is in the next tile's MFMAs: a SIMD's matrix pipe has the other
 //     wave's MFMAs while one wave is in its epilogue or in the split, and LDS / global latencies of one wave are covered by the other.
 // MFMAs are inline asm (operand classes and registers are this file's choice; an asm MFMA's wait states travel inside the
 // statement where the compiler could put a copy next to it), the pixels are their first operand (a lane's accumulators are one
@@ -297,11 +297,10 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
     asm volatile("" : "+v"(t_));      // (opaque: the row's addresses are computed here, not kept in registers across the MFMA loop)
     if (t_ < 2 * K_HROWS) convert_unit(parity, t_);
   };
-  auto convert_patches_ks1 = [&](int parity) {  // the four ks = 1 waves (256 threads, 384 units)
-    int t_ = tid - 256;
+  auto convert_own_slice = [&](int parity) {  // the four waves of a slice (256 threads) split its 192 rows
+    int t_ = tid & 255;
     asm volatile("" : "+v"(t_));
-    convert_unit(parity, t_);
-    if (t_ < 2 * K_HROWS - 256) convert_unit(parity, t_ + 256);
+    if (t_ < K_HROWS) convert_unit(parity, ks * K_HROWS + t_);
   };
 
   // prologue: my first tile's patches, split
@@ -497,14 +496,11 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
     }
     K_DRAIN();
     K_STAMP(1)
-#ifdef C64_STAMPS
-    if (k == 3) { st_[2] = st_[1]; st_[3] = st_[1]; }
-#endif
 
-    // The ks = 1 waves hand over their partial sums, request the next tile's residual into the freed accumulators, and split BOTH
-    // slices of the next tile's patches (landed: counters) while the ks = 0 waves - which started this tile behind the last one's
-    // epilogue - finish their MFMAs.  ONE barrier per tile: every wave's reads of this tile's patches are done, the next tile's
-    // patches are split, the partial sums are in place.
+    // Behind its MFMAs a wave splits ITS slice of the next tile's patches (landed: the slice's counter - its four waves transferred
+    // it); the ks = 1 waves first hand over their partial sums and afterwards request the next tile's residual into the freed
+    // accumulators.  ONE barrier per tile: every wave's reads of this tile's patches are done, the next tile's patches are split,
+    // the partial sums are in place.
     if (ks == 1) {
       K_AWAIT(cnt_addr + 8u, 4 * k)       // every epilogue wave has read the exchange area of the tile before
 #pragma unroll
@@ -515,14 +511,15 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
           v.x = acc[j][4 * q + 0]; v.y = acc[j][4 * q + 1]; v.z = acc[j][4 * q + 2]; v.w = acc[j][4 * q + 3];
           *reinterpret_cast<float4*>(smem + xch + j * 4096 + q * 1024) = v;
         }
-      if (dma_on) {
-        K_STAMP(2)
-        K_AWAIT(cnt_addr, 4 * (k + 1))
-        K_AWAIT(cnt_addr + 4u, 4 * (k + 1))
-        K_STAMP(3)
+    }
+    if (dma_on) {
+      K_STAMP(2)
+      K_AWAIT(cnt_addr + 4u * (unsigned)ks, 4 * (k + 1))
+      K_STAMP(3)
 #if !defined(K_ABL) || K_ABL != 1
-        convert_patches_ks1((k + 1) & 1);
+      convert_own_slice((k + 1) & 1);
 #endif
+      if (ks == 1) {
         K_RINI(f_tile)      // (behind the split: the accumulators are free registers for it; the requests land while I wait at the barrier)
       }
     }
