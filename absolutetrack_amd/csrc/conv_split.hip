@@ -455,8 +455,10 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
 #define SP_SLOTS3(CUR, NXT, N, FIRST) SP_SLOT(CUR, NXT, N, FIRST) SP_SLOT(CUR, NXT, (N) + 1, FIRST) SP_SLOT(CUR, NXT, (N) + 2, FIRST)
 #define SP_STEP(CUR, NXT, FIRST)                                                                     \
   {                                                                                                  \
+    __builtin_amdgcn_s_setprio(2);                                                                   \
     SP_SLOTS3(CUR, NXT, 0, FIRST) SP_SLOTS3(CUR, NXT, 3, FIRST)                                      \
     if constexpr (NM > 6) { SP_SLOTS3(CUR, NXT, 6, FIRST) SP_SLOTS3(CUR, NXT, 9, FIRST) }            \
+    __builtin_amdgcn_s_setprio(0);                                                                   \
   }
   static_assert(NM == 6 || NM == 12, "SP_STEP expands 6 or 12 slots");
   static_assert(NPH == 5, "SP_SLOT issues patch pieces 0..4");
@@ -704,7 +706,6 @@ hipError_t launch_conv_split(const ConvLaunch& c, hipStream_t s) {
   if ((size_t)c.n_img * c.H * c.W * c.cin * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
   if ((size_t)c.n_img * c.Ho * c.Wo * c.cout_store * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
   // layer2's 64 -> 64 convolutions: weights resident in registers (conv_c64r.hip)
-  if (conv_c64k_applicable(c)) return launch_conv_c64k(c, s);
   if (conv_c64r_applicable(c)) return launch_conv_c64r(c, s);
   // stride-1 3x3 from 64 input channels up (image rows of at most 31 pixels): the input halo resident in LDS
   const bool halo = c.ksize == 3 && c.stride == 1 && c.pad == 1 && c.cin >= 64 && c.W <= 31 && c.H == c.Ho && c.W == c.Wo;

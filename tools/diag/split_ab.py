@@ -142,8 +142,10 @@ cases = [("fp32 mfma", 0, lib), ("split f16x3", 1, lib)] + [(v, 1, l) for v, l i
 if cin == 64 and cout == 64 and ksize == 3 and stride == 1:
     cases += [("c64r (one wave/SIMD)", 2, lib), ("chunked 256x64 HALO", 3, lib)]
 times = {name: [] for name, _m, _l in cases}
-for rnd in range(10):
-    for name, mode, l in cases:
+import random
+random.seed(1)
+for rnd in range(int(os.environ.get("AB_ROUNDS", "10"))):
+    for name, mode, l in random.sample(cases, len(cases)):      # a new order every round: position effects average out
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(3):      # its own lead-in: the clock a case sees depends on what ran just before it (a case behind the slow fp32
             run(mode, l)        # kernel measured 10 % faster than the same code further down the list)
