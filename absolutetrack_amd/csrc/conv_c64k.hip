@@ -169,9 +169,7 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
   if (p.in_max) {
     bool ok;
     split_act_scale(p.in_max, x_scale, x_unscale, ok);
-#ifndef C64_STAMPS
     if (!ok && tid == 0 && blockIdx.x == 0 && p.status) atomicOr(p.status, UT_SPLIT_RANGE);
-#endif
   }
   const float tot_unscale = p.split_unscale * x_unscale;
 
@@ -431,12 +429,6 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
     K_PIN();                                                                                         \
   }
 
-#ifdef C64_STAMPS      /* tools/diag only: phase stamps of my fourth tile (wave C64_STAMPS - 1 of the pair writes), to p.status */
-  unsigned long long st_[8];
-#define K_STAMP(I) if (k == 3) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_[I]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
-#else
-#define K_STAMP(I)
-#endif
   for (int k = 0; k < my_tiles; ++k) {
     const int tile = blockIdx.x + k * grid;
     const unsigned rbuf = (unsigned)(((k & 1) * 2 + ks) * K_STAGE);
@@ -476,8 +468,6 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[j]));
-
-    K_STAMP(0)
     {
       u32x4k pxA[2][2], pxB[2][2];
       unsigned adE[2], adO[2];
@@ -495,7 +485,6 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
       K_STEP(8, 0, pxA, pxB, true, 99, adE, adO) K_STEP(8, 1, pxB, pxA, false, 99, adE, adO)
     }
     K_DRAIN();
-    K_STAMP(1)
 
     // Behind its MFMAs a wave splits ITS slice of the next tile's patches (landed: the slice's counter - its four waves transferred
     // it); the ks = 1 waves first hand over their partial sums and afterwards request the next tile's residual into the freed
@@ -513,18 +502,13 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
         }
     }
     if (dma_on) {
-      K_STAMP(2)
       K_AWAIT(cnt_addr + 4u * (unsigned)ks, 4 * (k + 1))
-      K_STAMP(3)
-#if !defined(K_ABL) || K_ABL != 1
       convert_own_slice((k + 1) & 1);
-#endif
       if (ks == 1) {
         K_RINI(f_tile)      // (behind the split: the accumulators are free registers for it; the requests land while I wait at the barrier)
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    K_STAMP(4)
     __builtin_amdgcn_s_barrier();
 
     if (ks == 0) {
@@ -563,13 +547,6 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my reads of the exchange area are done: my partner may write the next tile's
       K_SIGNAL(cnt_addr + 8u);
     }
-#ifdef C64_STAMPS
-    K_STAMP(5)
-    if (k == 3 && tid == 256 * (C64_STAMPS - 1) && p.status) {
-      unsigned long long* d = reinterpret_cast<unsigned long long*>(p.status) + blockIdx.x * 8;
-      for (int i = 0; i < 6; ++i) d[i] = st_[i];
-    }
-#endif
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (p.out_max) publish_abs_max(p.out_max, out_bits);
@@ -587,7 +564,6 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
 #undef K_W
 #undef K_STEP
 #undef K_MM
-#undef K_STAMP
 #undef K_OFF
 #undef K_ROFF
 #undef K_RINI

@@ -92,9 +92,7 @@ __global__ __launch_bounds__(256, 1) void conv_c64r_kernel(ConvLaunch p, int n_t
   if (p.in_max) {
     bool ok;
     split_act_scale(p.in_max, x_scale, x_unscale, ok);
-#ifndef C64_STAMPS
     if (!ok && tid == 0 && blockIdx.x == 0 && p.status) atomicOr(p.status, UT_SPLIT_RANGE);
-#endif
   }
   const float tot_unscale = p.split_unscale * x_unscale;
 
@@ -266,12 +264,6 @@ __global__ __launch_bounds__(256, 1) void conv_c64r_kernel(ConvLaunch p, int n_t
     C64_STEP(SLICE, 8, 0, pxA, pxB, true, 99) C64_STEP(SLICE, 8, 1, pxB, pxA, false, 99)             \
   }
 
-#ifdef C64_STAMPS      /* tools/diag only: phase stamps of my third tile's second run, to p.status */
-  unsigned long long st_[8];
-#define C64_STAMP(I) if (k == 2 && slice == 1) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_[I]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
-#else
-#define C64_STAMP(I)
-#endif
   int run = 0;
   for (int k = 0; k < my_tiles; ++k) {
     const int tile = blockIdx.x + k * grid;
@@ -319,14 +311,11 @@ __global__ __launch_bounds__(256, 1) void conv_c64r_kernel(ConvLaunch p, int n_t
           touch[j] = __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, m < M ? (unsigned)(m * COUT + 32 * cb) * 4u : C_OOB, 0, 0);
         }
       }
-      C64_STAMP(0)
       if (slice == 0) C64_RUN(0) else C64_RUN(1)
       asm volatile("" ::"v"(touch[0]), "v"(touch[1]), "v"(touch[2]), "v"(touch[3]));
-      C64_STAMP(1)
       // the patch of run + 1 (issued during run - 1) must have landed before it is split; this run's ten pieces may stay in flight
       if (dma_on) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C_PW) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      C64_STAMP(2)
 
       if (slice == 1) {
         // ---- epilogue: 1 / (weight scale x activation scale) x accumulator + bias + residual, ReLU, store.
@@ -369,7 +358,6 @@ __global__ __launch_bounds__(256, 1) void conv_c64r_kernel(ConvLaunch p, int n_t
 #undef C64_RES
 #undef C64_PIX
       }
-      C64_STAMP(3)
       if (run + 1 < n_runs) {
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();          // B1: every wave's pieces of the next patch have landed; this run's reads are done
@@ -377,13 +365,6 @@ __global__ __launch_bounds__(256, 1) void conv_c64r_kernel(ConvLaunch p, int n_t
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();          // B2: the next patch is split
       }
-#ifdef C64_STAMPS
-      C64_STAMP(4)
-      if (k == 2 && slice == 1 && tid == 0 && p.status) {
-        unsigned long long* d = reinterpret_cast<unsigned long long*>(p.status) + blockIdx.x * 8;
-        for (int i = 0; i < 5; ++i) d[i] = st_[i];
-      }
-#endif
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -397,7 +378,6 @@ __global__ __launch_bounds__(256, 1) void conv_c64r_kernel(ConvLaunch p, int n_t
 #undef C64_W
 #undef C64_STEP
 #undef C64_RUN
-#undef C64_STAMP
 }
 
 bool conv_c64r_applicable(const ConvLaunch& c) {

@@ -36,6 +36,36 @@ VARIANTS = {
     "nowait": [("      if (skip_waits > 0) --skip_waits;  ", "      if (p.k_pad >= 0) {} else if (skip_waits > 0) --skip_waits;  ")],
 }
 VARIANTS["noearlywait"] = [("      if constexpr (EARLY_RES) asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");", "")]
+# text patches of a COPY of conv_c64k.hip (the product source carries no timing code): C64_STAMPS=1|2 phase stamps of the fourth tile
+# of every workgroup (wave 0 / wave 4 of the workgroup writes), C64K_ABL=noconvert|noreads timing ablations (wrong numbers)
+C64K_STAMP = ('if (k == 3) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(st_[I]) :: "memory"); '
+              '__builtin_amdgcn_sched_barrier(0); }')
+def c64k_stamp_patches(which):
+    st = lambda i: C64K_STAMP.replace("[I]", f"[{i}]")
+    return [
+        ("    if (!ok && tid == 0 && blockIdx.x == 0 && p.status) atomicOr(p.status, UT_SPLIT_RANGE);\n", ""),      # p.status is the stamp buffer here
+        ("  for (int k = 0; k < my_tiles; ++k) {\n", "  unsigned long long st_[8];\n  for (int k = 0; k < my_tiles; ++k) {\n"),
+        ("    {\n      u32x4k pxA[2][2], pxB[2][2];", "    " + st(0) + "\n    {\n      u32x4k pxA[2][2], pxB[2][2];"),
+        ("    K_DRAIN();\n", "    K_DRAIN();\n    " + st(1) + "\n    if (k == 3) { st_[2] = st_[1]; st_[3] = st_[1]; }\n"),
+        ("      K_AWAIT(cnt_addr + 4u * (unsigned)ks, 4 * (k + 1))\n", "      " + st(2) + "\n      K_AWAIT(cnt_addr + 4u * (unsigned)ks, 4 * (k + 1))\n      " + st(3) + "\n"),
+        ("    asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n    __builtin_amdgcn_s_barrier();\n\n    if (ks == 0) {",
+         "    asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n    " + st(4) + "\n    __builtin_amdgcn_s_barrier();\n\n    if (ks == 0) {"),
+        ("      K_SIGNAL(cnt_addr + 8u);\n    }\n",
+         "      K_SIGNAL(cnt_addr + 8u);\n    }\n    " + st(5) + "\n    if (k == 3 && tid == %d && p.status) {\n      unsigned long long* d = reinterpret_cast<unsigned long long*>(p.status) + blockIdx.x * 8;\n"
+         "      for (int i = 0; i < 6; ++i) d[i] = st_[i];\n    }\n" % (256 * (which - 1))),
+    ]
+C64K_ABL = {
+    "noconvert": [("      convert_own_slice((k + 1) & 1);\n", "")],
+    "noreads": [("#define K_LOAD(DST, ADDR, S)                                                                         \\\n  {", "#define K_LOAD(DST, ADDR, S)                                                                         \\\n  if (p.k_pad < 0) {")],
+}
+def patched_c64k(name, patches):
+    text = open(os.path.join(CSRC, "conv_c64k.hip")).read()
+    for old, new in patches:
+        assert old in text, old
+        text = text.replace(old, new, 1)
+    path = f"/tmp/conv_c64k_{name}.hip"
+    open(path, "w").write(text)
+    return path
 variants = [v for v in os.environ.get("SPLIT_VARIANTS", "").split(",") if v]
 # SPLIT_ALT_SRC=<path>: another conv_split.hip (e.g. an earlier commit's, `git show <rev>:absolutetrack_amd/csrc/conv_split.hip`) as variant "alt"
 ALT_SRC = os.environ.get("SPLIT_ALT_SRC")
@@ -59,7 +89,7 @@ def build(name, patches, flags=(), alt=None, c64=None, c64k=None):
 
 
 if os.environ.get("C64_STAMPS"):      # phase stamps of conv_c64k.hip (fourth tile of every workgroup; 1: the epilogue wave of a pair, 2: the other)
-    lib = build("stamps", [], flags=["-DC64_STAMPS=" + os.environ["C64_STAMPS"]] + (["-DK_ABL=" + os.environ["K_ABL"]] if os.environ.get("K_ABL") else []))
+    lib = build("stamps", [], flags=["-DC64_STAMPS"], c64k=patched_c64k("stamps", c64k_stamp_patches(int(os.environ["C64_STAMPS"]))))
 else:
     lib = build("product", [], c64k=os.environ.get("C64K_MAIN_SRC"))      # C64K_MAIN_SRC=<path>: another conv_c64k.hip as the main build
 vlibs = {}
@@ -74,6 +104,8 @@ for v in variants:
 if ALT_SRC:
     vlibs["alt"] = build("alt", [], alt=ALT_SRC)
 # C64_ALT_SRCS=<path>,<path>: other versions of conv_c64r.hip (with the product conv_split.hip), timed beside the product as c64:<file>
+for nm in [q for q in os.environ.get("C64K_ABL", "").split(",") if q]:      # timing ablations of conv_c64k.hip (wrong numbers)
+    vlibs["c64k:" + nm] = build("c64k_" + nm, [], c64k=patched_c64k(nm, C64K_ABL[nm]))
 for path in [q for q in os.environ.get("C64K_ALT_SRCS", "").split(",") if q]:      # likewise for conv_c64k.hip
     nm = os.path.splitext(os.path.basename(path))[0]
     vlibs["c64k:" + nm] = build("c64k_" + nm, [], c64k=path)
