@@ -274,7 +274,8 @@ int pack_conv(ut_handle h, ConvW& cw, const float* w, const float* conv_bias, co
   if (rc) return rc;
   // fp16 planes for the split-fp16 kernels: the layers they take (channel slice == chunk width, >= 6 chunks: the 3x3
   // convolutions of the backbone; conv_split.hip from 64 channels out, conv_patch.hip's split instantiation for layer1)
-  if (cw.cslice == 32 && cw.k_pad / 32 >= 6 && cw.cout_store >= 32 && cw.cout_store % 4 == 0) {
+  // (and the 1x1 stride-2 shortcut of a 32-channel input: conv_c32s2.hip computes it beside the block's first convolution)
+  if (cw.cslice == 32 && (cw.k_pad / 32 >= 6 || (ksize == 1 && stride == 2 && cw.cin_pad == 32)) && cw.cout_store >= 32 && cw.cout_store % 4 == 0) {
     std::vector<uint16_t> planes((size_t)2 * cw.cout_pad * cw.k_pad);
     const float scale = ut::split_weight_scale(wp.data(), wp.size());
     cw.split_unscale = 1.0f / scale;
@@ -544,6 +545,39 @@ int run_block(ut_handle h, const Block& b, const float* x, float* tmp, float* ds
         }
         if (y_max) *y_max = bl.out_max;
         return UT_OK;
+      }
+      x_max = nullptr;
+    }
+  }
+  // layer2's entry in split-fp16 mode: the stride-2 3x3 and the 1x1 shortcut from one pass over x (conv_c32s2.hip)
+  if (h->call_split && h->block_fusion && x_max && !h->latency_mode && b.has_ds && b.conv1.w_split && b.ds.w_split && b.conv2.w_split &&
+      b.conv1.stride == 2 && b.conv1.cin_pad == 32 && b.conv1.cout_store == 64 && b.ds.cout_store == 64 && dsbuf) {
+    ut::Stride2Launch sl{};
+    sl.in = x; sl.out1 = tmp; sl.out2 = dsbuf; sl.w1_split = b.conv1.w_split; sl.wd_split = b.ds.w_split;
+    sl.unscale1 = b.conv1.split_unscale; sl.unscale_d = b.ds.split_unscale;
+    sl.bias1 = b.conv1.bias; sl.bias_d = b.ds.bias;
+    sl.in_max = x_max; sl.status = h->status;
+    sl.n_img = n_img; sl.H = H; sl.W = W; sl.device = h->device; sl.num_cu = h->num_cu;
+    if (ut::conv_c32s2_applicable(sl)) {
+      const unsigned gen = h->word_gen;
+      int word = 0;
+      if ((rc = next_launch_word(h, s, &word))) return rc;
+      if (gen == h->word_gen) {          // (a recycle in mid-call zeroed x's word: fall through to the separate launches)
+        sl.out1_max = h->counters + kMaxCounters + word;
+        ProfEvent pe{};
+        if (h->profiling) {
+          HIPCHK(h, hipEventCreateWithFlags(&pe.a, hipEventDisableSystemFence));
+          HIPCHK(h, hipEventCreateWithFlags(&pe.b, hipEventDisableSystemFence));
+          pe.flops = (b.conv1.flops_per_pixel + b.ds.flops_per_pixel) * (double)n_img * (H / 2) * (W / 2);
+          pe.kind = 1;
+          HIPCHK(h, hipEventRecord(pe.a, s));
+        }
+        HIPCHK(h, ut::launch_conv_c32s2(sl, s));
+        if (h->profiling) {
+          HIPCHK(h, hipEventRecord(pe.b, s));
+          h->prof.push_back(pe);
+        }
+        return run_conv(h, b.conv2, tmp, dsbuf, y, n_img, H / 2, W / 2, true, false, s, sl.out1_max, y_max);
       }
       x_max = nullptr;
     }

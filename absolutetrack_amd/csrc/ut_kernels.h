@@ -50,6 +50,25 @@ hipError_t launch_splitk_finish(const float* slabs, int n_splits, int m, int cou
 bool conv_split_applicable(const ConvLaunch& c);
 hipError_t launch_conv_split(const ConvLaunch& c, hipStream_t s);
 // 3x3 stride-1 64 -> 64 channels with the weights resident in registers, one wave per SIMD (conv_c64r.hip): same results
+// the stride-2 entry of layer2: BasicBlock's first convolution (3x3 / 2, 32 -> 64, BN, ReLU) and its shortcut (1x1 / 2, 32 -> 64, BN)
+// from one pass over the input (conv_c32s2.hip; split-fp16 arithmetic, weights resident in registers)
+struct Stride2Launch {
+  const float* in;          // [n_img][H][W][32]
+  float* out1;              // [n_img][H/2][W/2][64]: relu(bn1(conv1 x))
+  float* out2;              // [n_img][H/2][W/2][64]: bn_d(downsample x)
+  const void* w1_split;     // pack_split_weights planes of the 3x3 ([cout_pad / 32][9][...]) and of the 1x1 ([cout_pad / 32][1][...])
+  const void* wd_split;
+  float unscale1, unscale_d;      // 1 / (their weight scales)
+  const float* bias1;
+  const float* bias_d;
+  const unsigned* in_max;   // device word of max |in| (its producer's)
+  unsigned* out1_max;       // device word (zero before the launch): receives the bits of max |out1|
+  int* status;
+  int n_img, H, W;
+  int device, num_cu;
+};
+bool conv_c32s2_applicable(const Stride2Launch& c);
+hipError_t launch_conv_c32s2(const Stride2Launch& c, hipStream_t s);
 bool conv_c64k_applicable(const ConvLaunch& c);
 hipError_t launch_conv_c64k(const ConvLaunch& c, hipStream_t s);
 bool conv_c64r_applicable(const ConvLaunch& c);

@@ -24,6 +24,7 @@ def block_convs(bi, hw):
     return out, ho
 
 fused_l1 = any("conv_block32" in r["Kernel_Name"] for r in rows)   # split-fp16 mode: layer1's blocks are one launch each
+fused_s2 = any("conv_c32s2" in r["Kernel_Name"] for r in rows)     # ... and layer2's stride-2 3x3 + its 1x1 shortcut
 seq = []   # (name, flops for the launch)
 n_chunks = (n_crops + chunk - 1) // chunk
 for c in range(n_chunks):
@@ -33,6 +34,8 @@ for c in range(n_chunks):
         cs, hw = block_convs(bi, hw)
         if fused_l1 and bi < 2:
             cs = [(f"b{bi}.block 32->32->32 @{hw}", sum(fl for _, fl in cs))]
+        if fused_s2 and bi == 2:
+            cs = [(f"b2.conv1+ds 32->64 s2 @{hw}", cs[0][1] + cs[1][1]), cs[2]]
         seq += [(nm, fl * n) for nm, fl in cs]
 hw = 24
 for bi in range(5, 12):
@@ -45,7 +48,7 @@ head = [("fus0 144->108", 144 * 108), ("fus1 108->72", 108 * 72), ("fus2 72->72"
         ("reg1.conv1 76", 9 * 76 * 76), ("reg1.conv2 76", 9 * 76 * 76)]
 seq += [(nm, 2 * mac * 36 * s) for nm, mac in head]
 
-is_conv = lambda r: any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_c32_patch", "conv_split", "conv_block32", "conv_c64r", "conv_c64k"))
+is_conv = lambda r: any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_c32_patch", "conv_split", "conv_block32", "conv_c64r", "conv_c64k", "conv_c32s2"))
 
 
 def label(name):
@@ -56,6 +59,8 @@ def label(name):
         return "fused block 12x16 split f16"
     if "conv_c64r" in name:
         return "split f16 256x64 reg weights"
+    if "conv_c32s2" in name:
+        return "split f16 96px regW 3x3+1x1"
     if "conv_c64k" in name:
         return "split f16 128x64 regW K-split"
     if "conv3x3_c32_patch" in name:
