@@ -240,15 +240,16 @@ __global__ __launch_bounds__(512, 1) void conv_c32s2_kernel(Stride2Launch p, int
   auto issue_patch_piece = [&](int i, int first_pixel, int buf) {       // piece wave + 8 i
     const int q = wave_o + 8 * i;
     if (q < n_pieces) {
-      const int row = 8 * q + (lane_o >> 3);
+      const int pos = 8 * q + (lane_o >> 3);                                   // LDS row position of my 16 bytes
+      const int row = (pos & ~3) | ((pos & 1) << 1) | ((pos >> 1) & 1);        // ... holds patch row `row` (S_POS below)
       const int pix = first_pixel + row;
       const bool ok = pix >= 0 && pix < M_in && row < 9 * W;
-      const unsigned off = ok ? (unsigned)(pix * CIN + 4 * ((lane_o & 7) ^ ((row >> 1) & 7))) * 4u : S_HOOB;
+      const unsigned off = ok ? (unsigned)(pix * CIN + 4 * ((lane_o & 7) ^ ((row >> 2) & 7))) * 4u : S_HOOB;
       s2_dma(a_words, (unsigned)__builtin_amdgcn_readfirstlane((int)(smem_addr + (unsigned)(buf * S_STAGE + q * 1024))), off, 0u);
     }
   };
-  auto convert_row = [&](int buf, int row) {      // split a landed fp32 patch row in place (group q = k / 8 at q ^ swizzle)
-    const int sw = (row >> 1) & 7;
+  auto convert_row = [&](int buf, int row) {      // split the landed fp32 patch row at POSITION `row` in place (group q = k / 8 at q ^ swizzle)
+    const int sw = (row >> 2) & 7;
     char* rp = smem + buf * S_STAGE + row * 128;
     float4 f[8];
 #pragma unroll
@@ -267,15 +268,20 @@ __global__ __launch_bounds__(512, 1) void conv_c32s2_kernel(Stride2Launch p, int
       *reinterpret_cast<u32x4s*>(rp + (((4 + kg) ^ sw) << 4)) = b;
     }
   };
-  // rows of a patch: the two transfer waves take two rows per thread (256), the six MFMA waves the rest behind their MFMAs
+  // rows of a patch: the two transfer waves take two rows per thread (256), the six MFMA waves the rest behind their MFMAs.  Unit u
+  // -> row position: inside a group of 32 positions the lanes go 0, 1, 4, 5, 8, 9, ... then 2, 3, 6, 7, ...: sixteen lanes of a 16-byte
+  // access then cover both bank halves and eight different swizzles (positions in lane order would be a 2-way conflict with the
+  // (position >> 2) & 7 swizzle of this kernel)
+  auto unit_pos = [&](int u) { return (u & ~31) | (4 * ((u & 15) >> 1) + (u & 1) + 2 * ((u >> 4) & 1)); };
   auto convert_share = [&](int buf) {
     int t_ = tid;
     asm volatile("" : "+v"(t_));
     if (t_ >= 384) {
-      convert_row(buf, t_ - 384);
-      convert_row(buf, t_ - 384 + 128);
-    } else if (256 + t_ < 9 * W) {
-      convert_row(buf, 256 + t_);
+      convert_row(buf, unit_pos(t_ - 384));
+      convert_row(buf, unit_pos(t_ - 384 + 128));
+    } else {
+      const int pos = unit_pos(256 + t_);
+      if (256 + t_ < ((9 * W + 31) & ~31) && pos < 9 * W) convert_row(buf, pos);
     }
   };
 
@@ -322,11 +328,15 @@ __global__ __launch_bounds__(512, 1) void conv_c32s2_kernel(Stride2Launch p, int
 #define S_MFMA_V_LAST(ACC, WV, PXV) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 7" : "+v"(ACC) : "v"(PXV), "v"(WV))
 #define S_W(TAP, S, PL) (((TAP) * 4 + (S) * 2 + (PL)) & 31)
   // address of the lane's 16 bytes of tap TAP, k-step 0, first pieces - or in the block of zeros, on the same banks, when the tap
-  // leaves the image.  k-step 1 is that address ^ 32, the remainder pieces ^ 64.
+  // leaves the image.  k-step 1 is that address ^ 32, the remainder pieces ^ 64.  The lanes of a fragment read are patch rows TWO
+  // apart (stride 2): patch row r sits at LDS row position (r with its two low bits swapped), its 16-byte groups XOR-swizzled by
+  // (r >> 2) & 7 - sixteen lanes then cover both 128-byte bank halves and eight different groups (with rows in their natural
+  // order and the stride-1 kernels' (r >> 1) & 7 swizzle every read was a 2-way conflict).
 #define S_ADDR(DST, BUF, TAP)                                                                        \
   {                                                                                                  \
     const int row_ = lrow_t + ((TAP) / 3) * W + ((TAP) % 3);                                         \
-    const unsigned a_ = (unsigned)(BUF) + (unsigned)(row_ * 128) + (unsigned)(((fh ^ ((row_ >> 1) & 7))) << 4); \
+    const int pos_ = (row_ & ~3) | ((row_ & 1) << 1) | ((row_ >> 1) & 1);                            \
+    const unsigned a_ = (unsigned)(BUF) + (unsigned)(pos_ * 128) + (unsigned)(((fh ^ ((row_ >> 2) & 7))) << 4); \
     DST = ((rmask >> (TAP)) & 1u) ? a_ : (unsigned)S_ZROW + (a_ & 255u);                             \
   }
 #define S_LOAD(DST, ADDR, S)                                                                         \
@@ -366,11 +376,32 @@ __global__ __launch_bounds__(512, 1) void conv_c32s2_kernel(Stride2Launch p, int
       S_PIN();                                                                                       \
     }                                                                                                \
     if ((PIECE) < 7 && dma_on) issue_patch_piece(PIECE, f_first, f_buf);                             \
-    if ((PIECE) == 77 && dma_on) {      /* my pieces (issued 7+ k-steps ago) have landed */           \
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
+    if ((PIECE) == 77 && dma_on) {      /* my pieces (issued 7+ k-steps ago) have landed: count them in (later - behind the loop - */ \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* the splitting waves start later: measured + 8 %) */                \
       S_SIGNAL(cnt_addr);                                                                            \
     }                                                                                                \
     S_PIN();                                                                                         \
+  }
+
+  // ---- epilogues: the 3x3 (1 / scale x sum + bias, ReLU) and the shortcut (1 / scale x sum + bias): a lane owns ONE output channel
+  // (32 cb + fr) and sixteen pixels of the block (8 (r / 4) + 4 fh + r % 4): one dword store per accumulator register covers two
+  // whole 128-byte half rows; two per-lane offsets plus constants in the instruction's offset field.  The second MFMA wave of a
+  // SIMD (waves 4, 5) runs it BEFORE the tile's barrier, the first after it: one wave's stores under the other's MFMAs.
+#define S_ROFF(OFF, R) ((((R) >> 3) ? (OFF) + 16u * COUT * 4u : (OFF)) + (unsigned)(((((R) >> 2) & 1) * 8 + ((R) & 3)) * COUT * 4))
+#define S_EPILOGUE()                                                                                 \
+  {                                                                                                  \
+    const unsigned off = (unsigned)((tile * S_OPIX + 32 * blk + 4 * fh) * COUT + 32 * cb + fr) * 4u; \
+    unsigned mx = 0;                                                                                 \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                 \
+      const float o = fmaxf(__builtin_fmaf(acc[r], unscale1, bias1), 0.f);                           \
+      mx = max(mx, __float_as_uint(o));                                                              \
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), o1_rsrc, S_ROFF(off, r), 0, 0);      \
+    }                                                                                                \
+    out_bits = max(out_bits, mx);                                                                    \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                 \
+      const float o = __builtin_fmaf(accd[r], unscale_d, bias_d);                                    \
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), o2_rsrc, S_ROFF(off, r), 0, 0);      \
+    }                                                                                                \
   }
 
   f32x16s acc, accd;
@@ -408,6 +439,7 @@ __global__ __launch_bounds__(512, 1) void conv_c32s2_kernel(Stride2Launch p, int
         S_STEP(8, 0, pxB, pxA, 99, adO, adE)  S_STEP(8, 1, pxC, pxB, 99, adO, adE)
       }
       asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc), "+v"(accd));
+      if (wave >= 4) S_EPILOGUE();
     } else if (dma_on) {
 #pragma unroll
       for (int i = 0; i < 7; ++i) issue_patch_piece(i, f_first, f_buf);
@@ -422,27 +454,7 @@ __global__ __launch_bounds__(512, 1) void conv_c32s2_kernel(Stride2Launch p, int
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (mfma_wave) {
-      // ---- epilogues: the 3x3 (1 / scale x sum + bias, ReLU) and the shortcut (1 / scale x sum + bias): a lane owns ONE output channel
-      // (32 cb + fr) and sixteen pixels of the block (8 (r / 4) + 4 fh + r % 4): one dword store per accumulator register covers two
-      // whole 128-byte half rows; two per-lane offsets plus constants in the instruction's offset field
-      const unsigned off = (unsigned)((tile * S_OPIX + 32 * blk + 4 * fh) * COUT + 32 * cb + fr) * 4u;
-#define S_ROFF(OFF, R) ((((R) >> 3) ? (OFF) + 16u * COUT * 4u : (OFF)) + (unsigned)(((((R) >> 2) & 1) * 8 + ((R) & 3)) * COUT * 4))
-      unsigned mx = 0;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float o = fmaxf(__builtin_fmaf(acc[r], unscale1, bias1), 0.f);
-        mx = max(mx, __float_as_uint(o));
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), o1_rsrc, S_ROFF(off, r), 0, 0);
-      }
-      out_bits = max(out_bits, mx);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float o = __builtin_fmaf(accd[r], unscale_d, bias_d);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), o2_rsrc, S_ROFF(off, r), 0, 0);
-      }
-#undef S_ROFF
-    }
+    if (mfma_wave && wave < 4) S_EPILOGUE();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (p.out1_max) publish_abs_max(p.out1_max, out_bits);
@@ -458,6 +470,8 @@ __global__ __launch_bounds__(512, 1) void conv_c32s2_kernel(Stride2Launch p, int
 #undef S_ADDR
 #undef S_LOAD
 #undef S_STEP
+#undef S_EPILOGUE
+#undef S_ROFF
 }
 
 bool conv_c32s2_applicable(const Stride2Launch& c) {
