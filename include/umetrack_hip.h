@@ -117,7 +117,9 @@ int ut_set_conv_arithmetic(ut_handle h, int mode);
 /* Split-fp16 mode only: run each BasicBlock of layer1 (32 -> 32 -> 32 channels at 48x48) as ONE launch whose intermediate
  * relu(bn1(conv1 x)) stays in LDS (csrc/conv_block32.hip) instead of two convolution launches with a round trip through HBM
  * (1 = default).  Same arithmetic; the intermediate's power-of-two scale comes from a bound instead of the measured maximum,
- * so the two forms agree to the split arithmetic's rounding (~1e-7 relative), not bit for bit.  0 is for A/B tests. */
+ * so the two forms agree to the split arithmetic's rounding (~1e-7 relative), not bit for bit.  The same switch covers layer2's
+ * entry (csrc/conv_c32s2.hip: the block's stride-2 3x3 convolution and its 1x1 shortcut as one launch instead of a split-fp16 and
+ * an fp32 launch; the shortcut then runs in the split arithmetic too).  0 is for A/B tests. */
 int ut_set_block_fusion(ut_handle h, int on);
 
 /* Split-fp16 mode only: layer2's stride-1 64 -> 64 convolutions with the weights of an output block resident in registers.
