@@ -335,3 +335,27 @@ def test_landmark_memo_is_exact_and_invalidates():
     assert m.get(hm, 1, ja, xf) is None
     m.put(hm, 1, ja, xf, kp); m.put(hm, 0, ja, xf, kp); m.put(hm, 1, ja + 1, xf, kp)
     assert len(m.items) == 2 and m.get(hm, 1, ja, xf) is None             # capacity: oldest entry dropped
+
+
+@pytest.mark.parametrize("source", ["conv_c64k.hip", "conv_c32s2.hip"])
+def test_register_resident_kernels_keep_their_register_plan(tmp_path, source):
+    """conv_c64k.hip / conv_c32s2.hip keep 32 weight fragments pinned in the accumulator half of the register file and are written to
+    need no scratch: a compiler that moves a pinned fragment (v_accvgpr_*), spills (scratch_*) or gives the kernel fewer than two
+    waves per SIMD has broken the plan the kernels' speed - and, for values parked in registers the weights live in, their results -
+    rest on.  Also: no timing / ablation code in the product sources (tools/diag patches a copy)."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    import subprocess
+    csrc = os.path.join(os.path.dirname(os.path.abspath(_native.__file__)), "csrc")
+    text = open(os.path.join(csrc, source)).read()
+    assert "s_memtime" not in text and "STAMP" not in text and "ABL" not in text
+    out = tmp_path / "k.s"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage",
+                        "-I", csrc, os.path.join(csrc, source), "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = out.read_text()
+    assert "v_accvgpr" not in asm
+    assert "scratch_" not in asm
+    assert asm.count("v_mfma_f32_32x32x16_f16") in (108, 60)          # per wave and tile: 9 x 2 x 2 x 3, or 9 x 2 x 3 + 2 x 3
+    assert re.search(r"Occupancy \[waves/SIMD\]: 2", r.stderr)
