@@ -377,7 +377,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
     constexpr int pr_ = (N) / (MI * NI), ij_ = (N) % (MI * NI), i_ = ij_ / NI, j_ = ij_ % NI;        \
     constexpr int wp_ = pr_ == 0 ? 0 : pr_ == 1 ? 1 : 0;                                             \
     constexpr int xp_ = pr_ == 0 ? 1 : 0;                                                            \
-    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(wf[SET][j_][wp_]), frag(xp[SET][i_][xp_]), acc[i_][j_], 0, 0, 0); \
+    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(xp[SET][i_][xp_]), frag(wf[SET][j_][wp_]), acc[i_][j_], 0, 0, 0); \
   }
 
 #define SP_SIGNAL(ADDR, LGKM)                                                                         \
@@ -517,18 +517,29 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   // The residual of a tile: requested in front of the stores (see the epilogue); with 32-row waves (half the accumulators)
   // there are registers to request it a whole chunk ahead, under the tile's last MFMAs.
   constexpr bool EARLY_RES = MI * NI <= 2;
-  u32x4 rr[MI][NI][4];
+  // The pixels are the MFMAs' FIRST operand: a lane's sixteen accumulator registers of a 32 x 32 block are ONE output channel (fr) of
+  // sixteen pixels (8 (r / 4) + 4 fh + r % 4), so one dword access per register covers two whole 128-byte half rows of the
+  // [pixel][channel] tensor (with the weights first a lane owned a pixel and 16 of its channels: 16-byte accesses scattered over
+  // 32 rows per instruction, and the epilogue's loads and stores were a sixth of a 128-channel layer's time).
+  // Block (i, j), register r: pixel tm BM + SP_PIX(i, r), channel tn BN + (wn NI + j) 32 + fr.  A block's sixteen offsets are one
+  // per-lane base plus multiples of the pixel stride, walked with one add per access; pixels beyond the tensor (last tile) are beyond
+  // the descriptors' range - loads return zero, stores are dropped, no compare per access - and a channel beyond it (never, for the
+  // backbone's 64 / 128 / 256) starts from an offset that stays out of range under every such multiple.
+#define SP_PIX(I, R) (wm * (MI * 32) + (I) * 32 + 8 * ((R) >> 2) + 4 * fh + ((R) & 3))
+#define SP_BASE(TM, TN, J) ((TN) * BN + wn * (NI * 32) + (J) * 32 + fr < p.cout_store                   \
+                                ? (unsigned)(((TM) * BM + wm * (MI * 32) + 4 * fh) * p.cout_store + (TN) * BN + wn * (NI * 32) + (J) * 32 + fr) * 4u \
+                                : HOOB)
+  float rr[MI][NI][16];
 #define SP_RES_REQUEST()                                                                             \
   {                                                                                                  \
     const int tm_ = tile / tiles_n, tn_ = tile - tm_ * tiles_n;                                      \
-    _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                 \
-      const int m = tm_ * BM + wm * (MI * 32) + i * 32 + fr;                                         \
-      const bool m_ok = m < M;                                                                       \
-      _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                 \
-        _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4) {                                           \
-          const int n = tn_ * BN + wn * (NI * 32) + j * 32 + 8 * g4 + 4 * fh;                        \
-          const unsigned off = (m_ok && n < p.cout_store) ? (unsigned)(m * p.cout_store + n) * 4u : OOB; \
-          rr[i][j][g4] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0);                   \
+    const unsigned row_b_ = (unsigned)p.cout_store * 4u;                                             \
+    _Pragma("unroll") for (int j = 0; j < NI; ++j) {                                                 \
+      unsigned off_ = SP_BASE(tm_, tn_, j);                                                          \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                 \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
+          rr[i][j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_rsrc, off_, 0, 0));   \
+          off_ += ((r & 3) == 3 ? 5u : 1u) * row_b_;      /* 8 (r / 4) + r % 4: three single steps, then one of five */ \
         }                                                                                            \
     }                                                                                                \
   }
@@ -605,35 +616,29 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
     {
       const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
       const float floor_v = p.relu ? 0.f : -__builtin_huge_valf();
-      float4 bb[NI][4];
+      float bb[NI];
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4)
-          bb[j][g4] = *reinterpret_cast<const float4*>(p.bias + tn * BN + wn * (NI * 32) + j * 32 + 8 * g4 + 4 * fh);
+      for (int j = 0; j < NI; ++j) bb[j] = p.bias[tn * BN + wn * (NI * 32) + j * 32 + fr];
       if constexpr (!EARLY_RES) SP_RES_REQUEST();
       // skip_waits below relies on every transfer issued so far having landed once the epilogue has its operands.  Without
       // EARLY_RES the residual requests are the youngest operations, so the waits for them say so; with EARLY_RES they went
       // out in front of the last chunk's transfers: wait for everything here (bias and residual are needed now anyway).
       if constexpr (EARLY_RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned row_b = (unsigned)p.cout_store * 4u;
+      const bool ragged = tm * BM + BM > M;        // wave-uniform: only then the maximum needs the per-pixel mask
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int m = tm * BM + wm * (MI * 32) + i * 32 + fr;
-        const bool m_ok = m < M;
+      for (int j = 0; j < NI; ++j) {
+        unsigned off = SP_BASE(tm, tn, j);
+        const unsigned keep_n = off != HOOB ? 0x7FFFFFFFu : 0u;
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const int n = tn * BN + wn * (NI * 32) + j * 32 + 8 * g4 + 4 * fh;
-            const unsigned off = (m_ok && n < p.cout_store) ? (unsigned)(m * p.cout_store + n) * 4u : OOB;
-            const unsigned keep = off != OOB ? 0x7FFFFFFFu : 0u;     // rows / channels beyond the tensor do not count
-            u32x4 pk;
-            pk.x = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 0], tot_unscale, bb[j][g4].x + __uint_as_float(rr[i][j][g4].x)), floor_v));
-            pk.y = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 1], tot_unscale, bb[j][g4].y + __uint_as_float(rr[i][j][g4].y)), floor_v));
-            pk.z = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 2], tot_unscale, bb[j][g4].z + __uint_as_float(rr[i][j][g4].z)), floor_v));
-            pk.w = __float_as_uint(fmaxf(fmaf(acc[i][j][4 * g4 + 3], tot_unscale, bb[j][g4].w + __uint_as_float(rr[i][j][g4].w)), floor_v));
-            out_bits = max(max(out_bits, max(pk.x & keep, pk.y & keep)), max(pk.z & keep, pk.w & keep));
-            __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, off, 0, 0);
+          for (int r = 0; r < 16; ++r) {
+            const unsigned o = __float_as_uint(fmaxf(fmaf(acc[i][j][r], tot_unscale, bb[j] + rr[i][j][r]), floor_v));
+            const unsigned keep = ragged ? (tm * BM + SP_PIX(i, r) < M ? keep_n : 0u) : keep_n;     // pixels / channels beyond the tensor do not count
+            out_bits = max(out_bits, o & keep);
+            __builtin_amdgcn_raw_buffer_store_b32(o, o_rsrc, off, 0, 0);
+            off += ((r & 3) == 3 ? 5u : 1u) * row_b;
           }
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
@@ -666,6 +671,8 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
 #undef SP_MFMA
 #undef SP_SLOT
 #undef SP_RES_REQUEST
+#undef SP_PIX
+#undef SP_BASE
 #undef SP_SIGNAL
 #undef SP_AWAIT
 #undef SP_PEEK

@@ -35,6 +35,9 @@ VARIANTS = {
     # no counted vmcnt wait at the arrival (racy: timing only)
     "nowait": [("      if (skip_waits > 0) --skip_waits;  ", "      if (p.k_pad >= 0) {} else if (skip_waits > 0) --skip_waits;  ")],
 }
+# no output stores / no residual requests (wrong numbers): what the epilogue's memory operations cost
+VARIANTS["nostore"] = [("            __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, off, 0, 0);", "            if (p.k_pad < 0) __builtin_amdgcn_raw_buffer_store_b128(pk, o_rsrc, off, 0, 0);")]
+VARIANTS["nores"] = [("          rr[i][j][g4] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0);", "          rr[i][j][g4] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, OOB, 0, 0);")]
 VARIANTS["noearlywait"] = [("      if constexpr (EARLY_RES) asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");", "")]
 # text patches of a COPY of conv_c64k.hip (the product source carries no timing code): C64_STAMPS=1|2 phase stamps of the fourth tile
 # of every workgroup (wave 0 / wave 4 of the workgroup writes), C64K_ABL=noconvert|noreads timing ablations (wrong numbers)
