@@ -42,7 +42,8 @@ def build(name, patches, alt=None):
         open(src, "w").write(text)
     so = f"/tmp/libblockab_{name}.so"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w", "-DBLOCK_W4", *(["-DW4_STAMPS"] if STAMPS else []), "-o", so, src,
-                           W4_SRC, os.path.join(CSRC, "conv_split.hip"), os.path.join(ROOT, "tools", "diag", "block_entry.hip"), "-I", CSRC])
+                           W4_SRC, os.path.join(CSRC, "conv_split.hip"), os.path.join(CSRC, "conv_c64r.hip"), os.path.join(CSRC, "conv_c64k.hip"),
+                           os.path.join(ROOT, "tools", "diag", "block_entry.hip"), "-I", CSRC])
     return ctypes.CDLL(so)
 
 
@@ -118,9 +119,13 @@ if STAMPS:
     sys.exit(0)
 flops = 2.0 * n_img * hw * hw * 32 * 288 * 2
 times = {k: [] for k in libs}
-for rnd in range(10):
-    for name in libs:
+import random
+random.seed(1)
+for rnd in range(int(os.environ.get("AB_ROUNDS", "10"))):
+    for name in random.sample(list(libs), len(libs)):      # a new order every round, a lead-in per case: position effects average out
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            run(name)
         e0.record()
         for _ in range(4):
             run(name)
