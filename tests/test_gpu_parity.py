@@ -136,7 +136,9 @@ def test_split_f16_fused_layer1_blocks_match_the_two_launch_form(engine, split_e
     """conv_block32.hip (layer1's BasicBlocks as one launch each, the intermediate in LDS) against the same arithmetic as two
     convolution launches per block: the forms differ only in the intermediate's power-of-two scale (a bound there, the
     measured maximum here), i.e. in how the smallest values round - far inside the split arithmetic's own distance to fp32.
-    37 crops = 444 tiles on 256 persistent workgroups (the tile queue and the double-buffered patch are exercised)."""
+    37 crops = 444 tiles on 256 persistent workgroups (the tile queue and the double-buffered patch are exercised).  The same
+    switch turns off conv_c32s2.hip (layer2's stride-2 3x3 and its 1x1 shortcut as one launch: 222 tiles of 4 output rows here;
+    without it the shortcut is an fp32-instruction launch), so both fused kernels are held against their separate-launch forms."""
     crops = _dev(synth.synthetic_crops(37, seed=11))
     fused = split_engine.backbone(crops)
     split_engine.set_block_fusion(False)
