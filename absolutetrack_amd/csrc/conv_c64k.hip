@@ -398,7 +398,9 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
     }                                                                                                \
     K_PIN();                                                                                         \
   }
-#define K_STEP(TAP, S, CUR, NXT, HAVE_NEXT, PIECE, ADC, ADN)                                         \
+  // k-step (TAP, S) consumes CUR and reads the fragments of the k-step AFTER NEXT - (TAP + 1, S) - into FAR (three register sets in
+  // rotation); ADN holds the addresses of tap TAP + 1 (computed a k-step earlier), ADF receives those of tap TAP + 2 (S = 1)
+#define K_STEP(TAP, S, CUR, FAR, PIECE, ADN, ADF)                                                    \
   {                                                                                                  \
     u32x4k w8a_, w8b_;                                                                               \
     if constexpr ((TAP) == 8) {                                                                      \
@@ -406,19 +408,17 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
       w8b_ = *reinterpret_cast<const u32x4k*>(smem + w8 + ((S) * 2 + 1) * 1024);                     \
     }                                                                                                \
     K_MM(TAP, S, CUR, 0, 0)                                                                          \
-    if constexpr (HAVE_NEXT && (S) == 0) K_LOAD(NXT[0], ADC[0], 1);                                  \
-    if constexpr (HAVE_NEXT && (S) == 1) K_LOAD(NXT[0], ADN[0], 0);                                  \
+    if constexpr ((TAP) < 8) K_LOAD(FAR[0], ADN[0], S);                                              \
     K_PIN();                                                                                         \
     K_MM(TAP, S, CUR, 0, 1)                                                                          \
-    if constexpr (HAVE_NEXT && (S) == 0) K_LOAD(NXT[1], ADC[1], 1);                                  \
-    if constexpr (HAVE_NEXT && (S) == 1) K_LOAD(NXT[1], ADN[1], 0);                                  \
+    if constexpr ((TAP) < 8) K_LOAD(FAR[1], ADN[1], S);                                              \
     K_PIN();                                                                                         \
     K_MM(TAP, S, CUR, 0, 2)                                                                          \
     K_MM(TAP, S, CUR, 1, 0)                                                                          \
-    if constexpr ((S) == 0 && (TAP) < 8) K_ADDR(ADN[0], rbuf, 0, (TAP) + 1);                         \
+    if constexpr ((S) == 1 && (TAP) < 7) K_ADDR(ADF[0], rbuf, 0, (TAP) + 2);                         \
     K_PIN();                                                                                         \
     K_MM(TAP, S, CUR, 1, 1)                                                                          \
-    if constexpr ((S) == 0 && (TAP) < 8) K_ADDR(ADN[1], rbuf, 1, (TAP) + 1);                         \
+    if constexpr ((S) == 1 && (TAP) < 7) K_ADDR(ADF[1], rbuf, 1, (TAP) + 2);                         \
     K_PIN();                                                                                         \
     K_MM(TAP, S, CUR, 1, 2)                                                                          \
     if ((PIECE) < K_PW && dma_on) issue_patch_piece(PIECE, f_tile, f_buf);                           \
@@ -459,7 +459,8 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][e] = __builtin_fmaf(acc[j][e], inv_unscale, bias_scaled);
+        for (int e = 0; e < 16; ++e)      // (asm: the compiler vectorises this loop with a 32-register splat of bias_scaled that lives across the kernel)
+          asm("v_fma_f32 %0, %0, %1, %2" : "+v"(acc[j][e]) : "v"(inv_unscale), "v"(bias_scaled));
     } else {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -469,20 +470,25 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
 #pragma unroll
     for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[j]));
     {
-      u32x4k pxA[2][2], pxB[2][2];
+      u32x4k pxA[2][2], pxB[2][2], pxC[2][2];
       unsigned adE[2], adO[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) { K_ADDR(adE[j], rbuf, j, 0); K_LOAD(pxA[j], adE[j], 0); }
+      for (int j = 0; j < 2; ++j) {
+        K_ADDR(adE[j], rbuf, j, 0);
+        K_LOAD(pxA[j], adE[j], 0);
+        K_LOAD(pxB[j], adE[j], 1);
+        K_ADDR(adO[j], rbuf, j, 1);
+      }
       K_LEAD();
-      K_STEP(0, 0, pxA, pxB, true, 0, adE, adO)  K_STEP(0, 1, pxB, pxA, true, 1, adE, adO)
-      K_STEP(1, 0, pxA, pxB, true, 2, adO, adE)  K_STEP(1, 1, pxB, pxA, true, 3, adO, adE)
-      K_STEP(2, 0, pxA, pxB, true, 4, adE, adO)  K_STEP(2, 1, pxB, pxA, true, 5, adE, adO)
-      K_STEP(3, 0, pxA, pxB, true, 99, adO, adE) K_STEP(3, 1, pxB, pxA, true, 99, adO, adE)
-      K_STEP(4, 0, pxA, pxB, true, 99, adE, adO) K_STEP(4, 1, pxB, pxA, true, 99, adE, adO)
-      K_STEP(5, 0, pxA, pxB, true, 99, adO, adE) K_STEP(5, 1, pxB, pxA, true, 99, adO, adE)
-      K_STEP(6, 0, pxA, pxB, true, 99, adE, adO) K_STEP(6, 1, pxB, pxA, true, 99, adE, adO)
-      K_STEP(7, 0, pxA, pxB, true, 77, adO, adE) K_STEP(7, 1, pxB, pxA, true, 99, adO, adE)
-      K_STEP(8, 0, pxA, pxB, true, 99, adE, adO) K_STEP(8, 1, pxB, pxA, false, 99, adE, adO)
+      K_STEP(0, 0, pxA, pxC, 0, adO, adE)  K_STEP(0, 1, pxB, pxA, 1, adO, adE)
+      K_STEP(1, 0, pxC, pxB, 2, adE, adO)  K_STEP(1, 1, pxA, pxC, 3, adE, adO)
+      K_STEP(2, 0, pxB, pxA, 4, adO, adE)  K_STEP(2, 1, pxC, pxB, 5, adO, adE)
+      K_STEP(3, 0, pxA, pxC, 99, adE, adO)  K_STEP(3, 1, pxB, pxA, 99, adE, adO)
+      K_STEP(4, 0, pxC, pxB, 99, adO, adE)  K_STEP(4, 1, pxA, pxC, 99, adO, adE)
+      K_STEP(5, 0, pxB, pxA, 99, adE, adO)  K_STEP(5, 1, pxC, pxB, 99, adE, adO)
+      K_STEP(6, 0, pxA, pxC, 99, adO, adE)  K_STEP(6, 1, pxB, pxA, 99, adO, adE)
+      K_STEP(7, 0, pxC, pxB, 77, adE, adO)  K_STEP(7, 1, pxA, pxC, 99, adE, adO)
+      K_STEP(8, 0, pxB, pxA, 99, adO, adE)  K_STEP(8, 1, pxC, pxB, 99, adO, adE)
     }
     K_DRAIN();
 
