@@ -24,6 +24,7 @@ EXPORTS = (
     "ut_resample_homography", "ut_keypoint_metrics", "ut_profile_begin", "ut_profile_end", "ut_profile_end_by_kind",
     "ut_set_index_checks", "ut_poll_status", "ut_warp_backbone", "ut_set_latency_mode", "ut_set_conv_arithmetic",
     "ut_set_backbone_lanes", "ut_status_snapshot", "ut_warp_map", "ut_set_block_fusion", "ut_set_resident_weights",
+    "ut_canonical_backbone_weights",
 )
 
 UT_MODE_KNOWN, UT_MODE_UNKNOWN = 0, 1
@@ -111,6 +112,8 @@ def load_library() -> ctypes.CDLL:
     lib.ut_set_conv_arithmetic.argtypes = [vp, i32]
     lib.ut_poll_status.restype = i32
     lib.ut_poll_status.argtypes = [vp, vp]
+    lib.ut_canonical_backbone_weights.restype = i32
+    lib.ut_canonical_backbone_weights.argtypes = [vp, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     _lib = lib
     return lib
 
@@ -136,6 +139,23 @@ def state_dict_to_blob(state_dict) -> np.ndarray:
     blob = np.ascontiguousarray(np.concatenate(parts))
     assert blob.size == 4_259_410
     return blob
+
+
+def canonical_backbone_weights(state_dict) -> np.ndarray:
+    """The backbone's folded convolutions at their canonical channel scales, as ut_create packs them (host only: runs
+    without a GPU).  Layout: see ut_canonical_backbone_weights in include/umetrack_hip.h."""
+    lib = load_library()
+    blob = state_dict_to_blob(state_dict)
+    n = ctypes.c_size_t()
+    rc = lib.ut_canonical_backbone_weights(blob.ctypes.data_as(ctypes.c_void_p), blob.size, None, 0, ctypes.byref(n))
+    if rc != 0:
+        raise RuntimeError(f"ut_canonical_backbone_weights failed ({rc}): {lib.ut_last_error(None).decode()}")
+    out = np.empty(n.value, np.float32)
+    rc = lib.ut_canonical_backbone_weights(blob.ctypes.data_as(ctypes.c_void_p), blob.size,
+                                           out.ctypes.data_as(ctypes.c_void_p), out.size, ctypes.byref(n))
+    if rc != 0:
+        raise RuntimeError(f"ut_canonical_backbone_weights failed ({rc}): {lib.ut_last_error(None).decode()}")
+    return out
 
 
 def hand_model_blob(joint_rotation_axes, joint_rest_positions, landmark_rest_positions,
@@ -431,10 +451,10 @@ class HipEngine:
         """Split-fp16 mode: layer1's BasicBlocks as one launch each (default) or as two convolution launches (A/B tests)."""
         self._check(self.lib.ut_set_block_fusion(self._h, int(bool(on))), "ut_set_block_fusion")
 
-    def set_resident_weights(self, kind=1):
-        """Split-fp16 mode: layer2's 64 -> 64 convolutions with the weights resident in registers: 1 / True the K-split pair kernel
-        (default), 2 the one-wave-per-SIMD kernel (the chunked kernel's bits), 0 / False the chunked kernel of the other layers."""
-        self._check(self.lib.ut_set_resident_weights(self._h, int(kind)), "ut_set_resident_weights")
+    def set_resident_weights(self, on=True):
+        """Split-fp16 mode: layer2's 64 -> 64 convolutions with the weights resident in registers (conv_c64k.hip, the default)
+        or through the chunked kernel of the other layers (False: A/B tests)."""
+        self._check(self.lib.ut_set_resident_weights(self._h, int(bool(on))), "ut_set_resident_weights")
 
     def set_latency_mode(self, on: bool):
         """Few-crop launches split K across workgroups (per-frame tracking); results then agree with the default mode to

@@ -712,9 +712,8 @@ hipError_t launch_conv_split(const ConvLaunch& c, hipStream_t s) {
   if (!conv_split_applicable(c)) return hipErrorInvalidValue;
   if ((size_t)c.n_img * c.H * c.W * c.cin * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
   if ((size_t)c.n_img * c.Ho * c.Wo * c.cout_store * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
-  // layer2's 64 -> 64 convolutions: weights resident in registers (conv_c64k.hip; conv_c64r.hip on request)
+  // layer2's 64 -> 64 convolutions: weights resident in registers (conv_c64k.hip)
   if (conv_c64k_applicable(c)) return launch_conv_c64k(c, s);
-  if (conv_c64r_applicable(c)) return launch_conv_c64r(c, s);
   // stride-1 3x3 from 64 input channels up (image rows of at most 31 pixels): the input halo resident in LDS
   const bool halo = c.ksize == 3 && c.stride == 1 && c.pad == 1 && c.cin >= 64 && c.W <= 31 && c.H == c.Ho && c.W == c.Wo;
   if (c.cout_store <= 64) return halo ? launch_split_cfg<256, 64, 8, 1, true>(c, s) : launch_split_cfg<256, 64, 8, 1, false>(c, s);

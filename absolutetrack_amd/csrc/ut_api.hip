@@ -88,7 +88,7 @@ struct ut_context {
   int counter_next = 0;
   unsigned word_gen = 0;            // bumped by every zeroing of the words: a max word kept across launches is stale after it
   bool block_fusion = true;         // split-fp16 mode: layer1's BasicBlocks as one launch each (ut_set_block_fusion)
-  int resident_weights = 1;         // split-fp16 mode: layer2's 64 -> 64 convolutions: 1 conv_c64k, 2 conv_c64r, 0 the chunked kernel (ut_set_resident_weights)
+  int resident_weights = 1;         // split-fp16 mode: layer2's 64 -> 64 convolutions: 1 conv_c64k, 0 the chunked kernel (ut_set_resident_weights)
   bool call_split = false;          // the running backbone call uses the split-fp16 kernels (decided once per call)
   // index checks: device status words ([0] sticky errors, [1] per call), their pinned host mirror, the duplicate-slot
   // scratch (slots_cap ints, allocated with the temporal state) and the mode (UT_CHECK_*)
@@ -232,10 +232,86 @@ int upload(ut_handle h, const std::vector<float>& host, float** dev) {
   return UT_OK;
 }
 
-// Fold eval-mode BatchNorm (eps 1e-5) into the convolution and pack to [cout_pad][k_pad] with
-// k = slice*(taps*cslice) + tap*cslice + c (see ut_kernels.h).   y = s*(conv(x)+b-mean)+beta,  s = gamma/sqrt(var+eps)
-int pack_conv(ut_handle h, ConvW& cw, const float* w, const float* conv_bias, const BN* bn, int cin, int cout,
-              int ksize, int stride, int cout_store) {
+// One convolution with eval-mode BatchNorm (eps 1e-5) folded in, as the reference's tensors lay it out:
+//   y = s*(conv(x)+b-mean)+beta,  s = gamma/sqrt(var+eps)   ->   w[o][c][t] * s[o],  bias[o] = (b-mean)*s+beta
+// (fold in double, one rounding to fp32).
+struct Folded {
+  std::vector<float> w;      // [cout][cin][taps]
+  std::vector<float> b;      // [cout]
+  int cin = 0, cout = 0, taps = 0;
+};
+
+Folded fold_conv(const float* w, const float* conv_bias, const BN* bn, int cin, int cout, int taps) {
+  Folded f;
+  f.cin = cin; f.cout = cout; f.taps = taps;
+  f.w.resize((size_t)cout * cin * taps);
+  f.b.resize(cout);
+  for (int o = 0; o < cout; ++o) {
+    double s = 1.0, shift = conv_bias ? (double)conv_bias[o] : 0.0;
+    if (bn) {
+      s = (double)bn->g[o] / sqrt((double)bn->v[o] + 1e-5);
+      shift = (shift - (double)bn->m[o]) * s + (double)bn->b[o];
+    }
+    f.b[o] = (float)shift;
+    for (size_t i = (size_t)o * cin * taps; i < (size_t)(o + 1) * cin * taps; ++i) f.w[i] = (float)((double)w[i] * s);
+  }
+  return f;
+}
+
+// ---- channel canonicalisation (exact: powers of two only) --------------------------------------------------------------
+// relu(bn(conv)) commutes with a positive per-channel factor, and a power of two commutes with every fp32 rounding
+// (lib/models/backbone_resnet.py:56-72): scaling output channel c of a producer (its folded weight row and bias) by 2^k
+// and input channel c of every consumer (its weight column) by 2^-k leaves every later fp32 value bit for bit as it was.
+// A checkpoint fixes the scale of an inner channel only up to that freedom (a near-dead BatchNorm channel and the large
+// consumer weights that compensate it are the same function as a well-scaled pair), while the split-fp16 arithmetic keeps
+// ONE power-of-two scale per activation tensor and ONE per weight tensor: a channel 2^-18 below its tensor's largest has a
+// subnormal second piece.  So every channel is brought to a canonical scale at pack time: 2^k_c puts the largest magnitude
+// among the channel's producer rows (weights and bias) into [1, 2).  Two networks that differ by per-channel powers of two
+// pack to the same tensors, in both arithmetics.
+float row_max(const Folded& f, int o) {
+  float m = fabsf(f.b[o]);
+  const size_t n = (size_t)f.cin * f.taps;
+  for (size_t i = 0; i < n; ++i) {
+    const float a = fabsf(f.w[(size_t)o * n + i]);
+    m = a > m ? a : m;          // (a NaN never raises m: such a row keeps its scale)
+  }
+  return m;
+}
+int octave_shift(float m) {       // k with m * 2^k in [1, 2); 0 when the row is all zeros or not finite
+  if (!(m > 0.f) || !(m < INFINITY)) return 0;
+  return -ilogbf(m);
+}
+void scale_row(Folded& f, int o, int k) {
+  if (!k) return;
+  const size_t n = (size_t)f.cin * f.taps;
+  for (size_t i = 0; i < n; ++i) f.w[(size_t)o * n + i] = ldexpf(f.w[(size_t)o * n + i], k);
+  f.b[o] = ldexpf(f.b[o], k);
+}
+void scale_col(Folded& f, int c, int k) {
+  if (!k) return;
+  for (int o = 0; o < f.cout; ++o)
+    for (int t = 0; t < f.taps; ++t) {
+      float& v = f.w[((size_t)o * f.cin + c) * f.taps + t];
+      v = ldexpf(v, k);
+    }
+}
+// Channel c of one activation tensor: `keys` (a subset of its producers) define 2^k_c, every producer's row c is scaled by it
+// and every consumer's column c by its inverse.
+void canonicalise_channels(const std::vector<Folded*>& keys, const std::vector<Folded*>& producers,
+                           const std::vector<Folded*>& consumers) {
+  const int ch = keys[0]->cout;
+  for (int c = 0; c < ch; ++c) {
+    float m = 0.f;
+    for (Folded* p : keys) { const float r = row_max(*p, c); m = r > m ? r : m; }
+    const int k = octave_shift(m);
+    for (Folded* p : producers) scale_row(*p, c, k);
+    for (Folded* q : consumers) scale_col(*q, c, -k);
+  }
+}
+
+// Pack folded weights to [cout_pad][k_pad] with k = slice*(taps*cslice) + tap*cslice + c (see ut_kernels.h).
+int pack_conv(ut_handle h, ConvW& cw, const Folded& f, int ksize, int stride, int cout_store) {
+  const int cin = f.cin, cout = f.cout;
   cw.cin = cin; cw.cout = cout; cw.ksize = ksize; cw.stride = stride;
   cw.pad = ksize == 3 ? 1 : 0;
   cw.taps = ksize * ksize;
@@ -248,16 +324,11 @@ int pack_conv(ut_handle h, ConvW& cw, const float* w, const float* conv_bias, co
   cw.flops_per_pixel = 2.0 * cw.taps * cin * cout;
   std::vector<float> wp((size_t)cw.cout_pad * cw.k_pad, 0.f), bp(cw.cout_pad, 0.f);
   for (int o = 0; o < cout; ++o) {
-    double s = 1.0, shift = conv_bias ? (double)conv_bias[o] : 0.0;
-    if (bn) {
-      s = (double)bn->g[o] / sqrt((double)bn->v[o] + 1e-5);
-      shift = (shift - (double)bn->m[o]) * s + (double)bn->b[o];
-    }
-    bp[o] = (float)shift;
+    bp[o] = f.b[o];
     for (int c = 0; c < cin; ++c)
       for (int t = 0; t < cw.taps; ++t)
         wp[(size_t)o * cw.k_pad + (c / cw.cslice) * (cw.taps * cw.cslice) + t * cw.cslice + c % cw.cslice] =
-            (float)((double)w[((size_t)o * cin + c) * cw.taps + t] * s);
+            f.w[((size_t)o * cin + c) * cw.taps + t];
   }
   {
     double ws = 0.0, bm = 0.0;
@@ -289,7 +360,19 @@ int pack_conv(ut_handle h, ConvW& cw, const float* w, const float* conv_bias, co
   return upload(h, bp, &cw.bias);
 }
 
-int take_block(ut_handle h, Cursor& c, Block& b, int cin, int cout, int stride, bool ds) {
+int pack_conv(ut_handle h, ConvW& cw, const float* w, const float* conv_bias, const BN* bn, int cin, int cout,
+              int ksize, int stride, int cout_store) {
+  return pack_conv(h, cw, fold_conv(w, conv_bias, bn, cin, cout, ksize * ksize), ksize, stride, cout_store);
+}
+
+// A BasicBlock's folded convolutions.
+struct FoldedBlock {
+  Folded conv1, conv2, ds;
+  bool has_ds = false;
+  int stride = 1;
+};
+
+bool fold_block(Cursor& c, FoldedBlock& fb, int cin, int cout, int stride, bool ds) {
   const float* w1 = c.take((size_t)cout * cin * 9);
   BN bn1 = take_bn(c, cout);
   const float* w2 = c.take((size_t)cout * cout * 9);
@@ -297,13 +380,96 @@ int take_block(ut_handle h, Cursor& c, Block& b, int cin, int cout, int stride, 
   const float* wd = nullptr;
   BN bnd;
   if (ds) { wd = c.take((size_t)cout * cin); bnd = take_bn(c, cout); }
-  if (!c.ok) return fail(h, UT_E_WEIGHTS, "weight blob too short");
+  if (!c.ok) return false;
+  fb.stride = stride; fb.has_ds = ds;
+  fb.conv1 = fold_conv(w1, nullptr, &bn1, cin, cout, 9);
+  fb.conv2 = fold_conv(w2, nullptr, &bn2, cout, cout, 9);
+  if (ds) fb.ds = fold_conv(wd, nullptr, &bnd, cin, cout, 1);
+  return true;
+}
+
+// the block's inner channels: conv1 writes them, conv2 reads them (conv1's input channels must have their final scale)
+void canonicalise_inner(FoldedBlock& fb) { canonicalise_channels({&fb.conv1}, {&fb.conv1}, {&fb.conv2}); }
+
+int pack_block(ut_handle h, Block& b, const FoldedBlock& fb) {
   int rc;
-  if ((rc = pack_conv(h, b.conv1, w1, nullptr, &bn1, cin, cout, 3, stride, round_up(cout, 4)))) return rc;
-  if ((rc = pack_conv(h, b.conv2, w2, nullptr, &bn2, cout, cout, 3, 1, round_up(cout, 4)))) return rc;
-  b.has_ds = ds;
-  if (ds && (rc = pack_conv(h, b.ds, wd, nullptr, &bnd, cin, cout, 1, stride, round_up(cout, 4)))) return rc;
+  const int cs = round_up(fb.conv1.cout, 4);
+  if ((rc = pack_conv(h, b.conv1, fb.conv1, 3, fb.stride, cs))) return rc;
+  if ((rc = pack_conv(h, b.conv2, fb.conv2, 3, 1, cs))) return rc;
+  b.has_ds = fb.has_ds;
+  if (fb.has_ds && (rc = pack_conv(h, b.ds, fb.ds, 1, fb.stride, cs))) return rc;
   return UT_OK;
+}
+
+// stem + ResNet "2352" + projection, folded, with canonical channel scales
+struct FoldedBackbone {
+  Folded stem, proj;
+  FoldedBlock fb[12];
+};
+
+bool fold_backbone(Cursor& c, FoldedBackbone& out) {
+  // stem (lib/models/model_utils.py:119-124)
+  const float* sw = c.take(32 * 9);
+  const float* sb = c.take(32);
+  BN sbn = take_bn(c, 32);
+  if (!c.ok) return false;
+  Folded& stem = out.stem;
+  Folded& proj = out.proj;
+  FoldedBlock* fb = out.fb;
+  stem = fold_conv(sw, sb, &sbn, 1, 32, 9);
+  // ResNet layers "2352", planes 32/64/128/256, strides 1/2/2/2 (lib/models/backbone_resnet.py:168-192)
+  const int nb[4] = {2, 3, 5, 2}, planes[4] = {32, 64, 128, 256}, strides[4] = {1, 2, 2, 2};
+  int first_of_layer[5] = {0, 0, 0, 0, 12};
+  int cin = 32, bi = 0;
+  for (int l = 0; l < 4; ++l) {
+    first_of_layer[l] = bi;
+    for (int k = 0; k < nb[l]; ++k) {
+      int st = k == 0 ? strides[l] : 1;
+      bool ds = k == 0 && (st != 1 || cin != planes[l]);
+      if (!fold_block(c, fb[bi++], cin, planes[l], st, ds)) return false;
+      cin = planes[l];
+    }
+  }
+  const float* pw = c.take(72 * 256); const float* pb = c.take(72);
+  if (!c.ok) return false;
+  proj = fold_conv(pw, pb, nullptr, 256, 72, 1);
+  // Canonical channel scales, fixed in network order so that each one is defined by tensors whose input side is final
+  // already (two checkpoints that differ by per-channel powers of two then arrive at the same tensors):
+  //  - the TRUNK of a layer (the tensor its identity shortcuts carry through the blocks): channel c is written by conv2 of
+  //    every block of the layer and by the first block's shortcut convolution (layer1: by the stem) and read by conv1 of the
+  //    layer's later blocks and by whatever enters the next layer (its first block's conv1 and shortcut convolution; after
+  //    layer4: the projection, whose 72 outputs are the features of the ABI and keep their scale).  Its scale comes from the
+  //    rows that write the trunk's FIRST tensor: the stem's, or the first block's shortcut and conv2 rows;
+  //  - the inner channels of every block, once the block's input has its scale.
+  for (int l = 0; l < 4; ++l) {
+    const int b0 = first_of_layer[l], b1 = l < 3 ? first_of_layer[l + 1] : 12;
+    std::vector<Folded*> keys, prod, cons;
+    if (fb[b0].has_ds) {
+      canonicalise_inner(fb[b0]);             // its input is the previous layer's trunk: final
+      keys = {&fb[b0].ds, &fb[b0].conv2};
+      prod = {&fb[b0].ds};
+    } else {
+      keys = {&stem};
+      prod = {&stem};
+      cons.push_back(&fb[b0].conv1);
+    }
+    for (int b = b0; b < b1; ++b) {
+      prod.push_back(&fb[b].conv2);
+      if (b > b0) cons.push_back(&fb[b].conv1);
+    }
+    if (l < 3) { cons.push_back(&fb[b1].conv1); cons.push_back(&fb[b1].ds); }
+    else cons.push_back(&proj);
+    canonicalise_channels(keys, prod, cons);
+    for (int b = fb[b0].has_ds ? b0 + 1 : b0; b < b1; ++b) canonicalise_inner(fb[b]);
+  }
+  return true;
+}
+
+int take_block(ut_handle h, Cursor& c, Block& b, int cin, int cout, int stride, bool ds) {
+  FoldedBlock fb;
+  if (!fold_block(c, fb, cin, cout, stride, ds)) return fail(h, UT_E_WEIGHTS, "weight blob too short");
+  canonicalise_inner(fb);
+  return pack_block(h, b, fb);
 }
 
 int take_regressor(ut_handle h, Cursor& c, Regressor& r, int ch, int d) {
@@ -449,7 +615,7 @@ int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, fl
   c.k_total = cw.k_total; c.k_pad = cw.k_pad; c.cslice = cw.cslice;
   c.ksize = cw.ksize; c.stride = cw.stride; c.pad = cw.pad;
   c.relu = relu; c.out_nchw = nchw;
-  c.device = h->device; c.num_cu = h->num_cu; c.no_resident = h->resident_weights == 0 ? 1 : h->resident_weights == 2 ? 2 : 0;
+  c.device = h->device; c.num_cu = h->num_cu; c.no_resident = h->resident_weights == 0 ? 1 : 0;
   int word = 0;
   {
     const unsigned gen = h->word_gen;
@@ -601,6 +767,30 @@ size_t ut_weight_blob_floats(void) { return UT_WEIGHT_BLOB_FLOATS; }
 
 const char* ut_last_error(ut_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+int ut_canonical_backbone_weights(const float* blob, size_t n_floats, float* out, size_t out_floats, size_t* n_out) {
+  if (!blob || !n_out) return fail(nullptr, UT_E_INVALID, "ut_canonical_backbone_weights: null argument");
+  if (n_floats != UT_WEIGHT_BLOB_FLOATS) return fail(nullptr, UT_E_WEIGHTS, "ut_canonical_backbone_weights: weight blob has the wrong length");
+  Cursor c{blob, n_floats};
+  FoldedBackbone fbb;
+  if (!fold_backbone(c, fbb)) return fail(nullptr, UT_E_WEIGHTS, "weight blob too short");
+  std::vector<const Folded*> all = {&fbb.stem};
+  for (const FoldedBlock& b : fbb.fb) {
+    all.push_back(&b.conv1); all.push_back(&b.conv2);
+    if (b.has_ds) all.push_back(&b.ds);
+  }
+  all.push_back(&fbb.proj);
+  size_t n = 0;
+  for (const Folded* f : all) n += f->w.size() + f->b.size();
+  *n_out = n;
+  if (!out) return UT_OK;
+  if (out_floats < n) return fail(nullptr, UT_E_INVALID, "ut_canonical_backbone_weights: output too small");
+  for (const Folded* f : all) {
+    memcpy(out, f->w.data(), f->w.size() * sizeof(float)); out += f->w.size();
+    memcpy(out, f->b.data(), f->b.size() * sizeof(float)); out += f->b.size();
+  }
+  return UT_OK;
+}
+
 int ut_create(int device, const float* blob, size_t n_floats, ut_handle* out) {
   if (!blob || !out) return fail(nullptr, UT_E_INVALID, "ut_create: null argument");
   if (n_floats != UT_WEIGHT_BLOB_FLOATS) return fail(nullptr, UT_E_WEIGHTS, "ut_create: weight blob has the wrong length");
@@ -615,36 +805,20 @@ int ut_create(int device, const float* blob, size_t n_floats, ut_handle* out) {
   Cursor c{blob, n_floats};
   int rc = UT_OK;
   do {
-    // stem (lib/models/model_utils.py:119-124)
-    const float* sw = c.take(32 * 9);
-    const float* sb = c.take(32);
-    BN sbn = take_bn(c, 32);
-    std::vector<float> w(32 * 9), b(32);
-    for (int o = 0; o < 32; ++o) {
-      double s = (double)sbn.g[o] / sqrt((double)sbn.v[o] + 1e-5);
-      for (int t = 0; t < 9; ++t) w[o * 9 + t] = (float)((double)sw[o * 9 + t] * s);
-      b[o] = (float)(((double)sb[o] - (double)sbn.m[o]) * s + (double)sbn.b[o]);
-    }
-    if ((rc = upload(h, w, &h->stem_w)) || (rc = upload(h, b, &h->stem_b))) break;
     { float* cnt = nullptr; if ((rc = dev_alloc(h, &cnt, 2 * kMaxCounters))) break; h->counters = (unsigned*)cnt; }
     { float* st = nullptr; if ((rc = dev_alloc(h, &st, 2))) break; h->status = (int*)st;
       hipError_t e2 = hipMemset(h->status, 0, 2 * sizeof(int));
       if (e2 == hipSuccess) e2 = hipHostMalloc((void**)&h->status_host, 2 * sizeof(int), hipHostMallocDefault);
       if (e2 != hipSuccess) { rc = fail(h, UT_E_HIP, "status words", e2); break; } }
-    // ResNet layers "2352", planes 32/64/128/256, strides 1/2/2/2 (lib/models/backbone_resnet.py:168-192)
-    const int nb[4] = {2, 3, 5, 2}, planes[4] = {32, 64, 128, 256}, strides[4] = {1, 2, 2, 2};
-    int cin = 32, bi = 0;
-    for (int l = 0; l < 4 && !rc; ++l)
-      for (int k = 0; k < nb[l] && !rc; ++k) {
-        int st = k == 0 ? strides[l] : 1;
-        bool ds = k == 0 && (st != 1 || cin != planes[l]);
-        rc = take_block(h, c, h->bb[bi++], cin, planes[l], st, ds);
-        cin = planes[l];
-      }
+    FoldedBackbone fbb;
+    if (!fold_backbone(c, fbb)) { rc = fail(h, UT_E_WEIGHTS, "weight blob too short"); break; }
+    const Folded& stem = fbb.stem;
+    const Folded& proj = fbb.proj;
+    const FoldedBlock* fb = fbb.fb;
+    if ((rc = upload(h, stem.w, &h->stem_w)) || (rc = upload(h, stem.b, &h->stem_b))) break;
+    for (int b = 0; b < 12 && !rc; ++b) rc = pack_block(h, h->bb[b], fb[b]);
     if (rc) break;
-    const float* pw = c.take(72 * 256); const float* pb = c.take(72);
-    if (!c.ok) { rc = fail(h, UT_E_WEIGHTS, "weight blob too short"); break; }
-    if ((rc = pack_conv(h, h->proj, pw, pb, nullptr, 256, 72, 1, 1, 72))) break;
+    if ((rc = pack_conv(h, h->proj, proj, 1, 1, 72))) break;
     // fusion 144 -> 108 -> 72 -> 72 (lib/models/model_utils.py:141-163)
     { const float* w0 = c.take(108 * 144); const float* b0 = c.take(108); BN bn0 = take_bn(c, 108);
       const float* w1 = c.take(72 * 108); const float* b1 = c.take(72); BN bn1 = take_bn(c, 72);
@@ -1133,7 +1307,7 @@ int ut_set_block_fusion(ut_handle h, int on) {
 
 int ut_set_resident_weights(ut_handle h, int on) {
   if (!h) return UT_E_INVALID;
-  if (on < 0 || on > 2) return fail(h, UT_E_INVALID, "ut_set_resident_weights: bad argument");
+  if (on < 0 || on > 1) return fail(h, UT_E_INVALID, "ut_set_resident_weights: bad argument");
   h->resident_weights = on;
   return UT_OK;
 }

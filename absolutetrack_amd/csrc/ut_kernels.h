@@ -36,8 +36,7 @@ struct ConvLaunch {
   int device;          // HIP device the launch goes to (the dynamic-LDS attribute is set once per device)
   int num_cu;          // compute units of the device (persistent grid sizing)
   unsigned* tile_counter;   // device word, zero before the launch: dynamic tile queue of the persistent grid
-  int no_resident;     // split kernels: 1 = never a register-resident-weights kernel (ut_set_resident_weights(h, 0)); 2 = the one-wave-
-                       // per-SIMD form (conv_c64r.hip) instead of the K-split pair form (conv_c64k.hip) - A/B tests
+  int no_resident;     // split kernels: 1 = never the register-resident-weights kernel (ut_set_resident_weights(h, 0): A/B tests)
   int splits;          // > 1 (latency mode): K is cut in `splits` equal chunk ranges, out = [splits][M][cout_store] slabs;
                        // 1 = latency mode without a split (prefers small tiles); 0 = throughput dispatch
 };
@@ -49,7 +48,6 @@ hipError_t launch_splitk_finish(const float* slabs, int n_splits, int m, int cou
 // the same convolution on the fp16 matrix cores from two-piece splits of both operands (conv_split.hip)
 bool conv_split_applicable(const ConvLaunch& c);
 hipError_t launch_conv_split(const ConvLaunch& c, hipStream_t s);
-// 3x3 stride-1 64 -> 64 channels with the weights resident in registers, one wave per SIMD (conv_c64r.hip): same results
 // the stride-2 entry of layer2: BasicBlock's first convolution (3x3 / 2, 32 -> 64, BN, ReLU) and its shortcut (1x1 / 2, 32 -> 64, BN)
 // from one pass over the input (conv_c32s2.hip; split-fp16 arithmetic, weights resident in registers)
 struct Stride2Launch {
@@ -69,10 +67,9 @@ struct Stride2Launch {
 };
 bool conv_c32s2_applicable(const Stride2Launch& c);
 hipError_t launch_conv_c32s2(const Stride2Launch& c, hipStream_t s);
+// 3x3 stride-1 64 -> 64 channels with the weights resident in registers, K split across the two waves of a SIMD (conv_c64k.hip)
 bool conv_c64k_applicable(const ConvLaunch& c);
 hipError_t launch_conv_c64k(const ConvLaunch& c, hipStream_t s);
-bool conv_c64r_applicable(const ConvLaunch& c);
-hipError_t launch_conv_c64r(const ConvLaunch& c, hipStream_t s);
 size_t pack_split_weights(const float* w, int cout_pad, int k_pad, float scale, uint16_t* out);
 float split_weight_scale(const float* w, size_t n);
 // One 32 -> 32 -> 32 channel BasicBlock (stride 1, no shortcut convolution) in one launch, split-fp16 arithmetic

@@ -175,3 +175,59 @@ def synthetic_frames(f: int, n_cams: int = 4, h: int = 480, w: int = 636, seed: 
             img = 0.7 * smooth + 0.3 * noise[c]
             out[i, c] = np.clip(np.floor(img * 256.0), 0, 255).astype(np.uint8)
     return out
+
+
+def channel_rescaled_state_dict(sd: Dict[str, np.ndarray], spread: int, seed: int = 0, inner: bool = True,
+                                trunk: bool = True) -> Dict[str, np.ndarray]:
+    """The same fp32 function as `sd`, written with other per-channel scales inside the backbone: every inner channel c of
+    every BasicBlock (bn1 output / conv2 input) is divided by 2^k_c - bn1.{weight,bias}[c] x 2^-k_c, conv2.weight[:, c] x 2^k_c
+    - and every trunk channel of a layer (stem / bn2 / downsample-bn rows of channel c across the layer's blocks; conv1 columns
+    of the layer's later blocks and of whatever reads the layer: the next layer's first conv1 and shortcut, the projection) by
+    2^t_c, with k_c, t_c independent random integers in [-spread, spread].  Powers of two commute with ReLU and every fp32
+    rounding (lib/models/backbone_resnet.py:56-72), so an exact-fp32 implementation returns the same bits for both; a near-dead
+    BatchNorm channel whose consumer weights compensate is the trained-checkpoint case this stands for."""
+    out = dict(sd)
+    pre = "_feature_extractor._image_backbone.0._layers."
+    nb = [2, 3, 5, 2]
+    planes = [32, 64, 128, 256]
+
+    def ints(tag, n):
+        u = counter_uniform("rescale." + tag, n, seed)
+        return np.floor(u * (2 * spread + 1)).astype(np.int64) - spread
+
+    def mul(key, factor, axis):
+        v = out[key]
+        shape = [1] * v.ndim
+        shape[axis] = -1
+        out[key] = (v * factor.reshape(shape)).astype(np.float32)
+
+    for li in range(4):
+        l = li + 1
+        ch = planes[li]
+        if trunk:
+            t = ints(f"trunk.{l}", ch)
+            down, up = np.exp2(-t).astype(np.float32), np.exp2(t).astype(np.float32)
+            if l == 1:
+                mul(pre + "0.1.weight", down, 0)
+                mul(pre + "0.1.bias", down, 0)
+            else:
+                mul(pre + f"{l}.0.downsample.1.weight", down, 0)
+                mul(pre + f"{l}.0.downsample.1.bias", down, 0)
+            for b in range(nb[li]):
+                mul(pre + f"{l}.{b}.bn2.weight", down, 0)
+                mul(pre + f"{l}.{b}.bn2.bias", down, 0)
+                if b > 0 or l == 1:
+                    mul(pre + f"{l}.{b}.conv1.weight", up, 1)
+            if l < 4:
+                mul(pre + f"{l + 1}.0.conv1.weight", up, 1)
+                mul(pre + f"{l + 1}.0.downsample.0.weight", up, 1)
+            else:
+                mul("_feature_extractor._image_backbone.1.weight", up, 1)
+        if inner:
+            for b in range(nb[li]):
+                k = ints(f"inner.{l}.{b}", ch)
+                down, up = np.exp2(-k).astype(np.float32), np.exp2(k).astype(np.float32)
+                mul(pre + f"{l}.{b}.bn1.weight", down, 0)
+                mul(pre + f"{l}.{b}.bn1.bias", down, 0)
+                mul(pre + f"{l}.{b}.conv2.weight", up, 1)
+    return out

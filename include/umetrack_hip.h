@@ -71,6 +71,17 @@ size_t ut_weight_blob_floats(void);
  * weights_blob is a HOST pointer.  BatchNorm is folded and the weights are packed for the
  * kernels here, once. */
 int ut_create(int device, const float* weights_blob, size_t n_floats, ut_handle* out);
+
+/* Host only (no device is touched): the backbone's convolutions as ut_create packs them - BatchNorm folded
+ * (lib/models/backbone_resnet.py:56-72 in eval mode) and every inner channel brought to its canonical power-of-two scale:
+ * output channel c of a producer (folded weight row and bias) times 2^k_c, input channel c of its consumers times 2^-k_c,
+ * with 2^k_c putting the largest magnitude of the channel's defining rows into [1, 2).  Powers of two commute with ReLU and
+ * with every fp32 rounding, so the packed network computes the checkpoint's fp32 values bit for bit, and two checkpoints that
+ * differ by per-channel powers of two (a near-dead BatchNorm channel whose consumer weights compensate, say) pack to the SAME
+ * tensors - the split-fp16 arithmetic, which keeps one power-of-two scale per tensor, therefore sees the same network.
+ * out (may be NULL: only *n_out is set) receives, as fp32: stem w[32][1][9] b[32] | for each of the 12 BasicBlocks conv1
+ * w[cout][cin][9] b[cout], conv2 w b, and the shortcut w[cout][cin][1] b where the block has one | projection w[72][256][1] b. */
+int ut_canonical_backbone_weights(const float* weights_blob, size_t n_floats, float* out, size_t out_floats, size_t* n_out);
 int ut_destroy(ut_handle h);
 const char* ut_last_error(ut_handle h);   /* h may be NULL: error of the last failed ut_create */
 
@@ -125,8 +136,8 @@ int ut_set_block_fusion(ut_handle h, int on);
 /* Split-fp16 mode only: layer2's stride-1 64 -> 64 convolutions with the weights of an output block resident in registers.
  * 1 (default): csrc/conv_c64k.hip - two waves per SIMD share an output block and split its K; their partial sums are added
  *    (slice 0) + (slice 1), so results agree with the chunked kernel's single running sum to fp32 rounding, not bit for bit.
- * 2: csrc/conv_c64r.hip - one wave per SIMD, one running sum: the chunked kernel's bits.
- * 0: the chunked kernel every other layer uses.  0 and 2 are for A/B tests. */
+ * 0: the chunked kernel every other layer uses (for A/B tests; its one-wave-per-SIMD predecessor conv_c64r.hip, which has the
+ *    chunked kernel's bits, lives under tools/diag/ with its bit-equality check in tools/diag/split_ab.py). */
 int ut_set_resident_weights(ut_handle h, int on);
 
 /* Latency mode for calls on a handful of crops (the per-frame tracker): convolutions whose launch has far fewer tiles

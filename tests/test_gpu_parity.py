@@ -106,25 +106,21 @@ def test_split_f16_backbone_matches_oracle(engine, split_engine):
 
 
 @pytest.mark.parametrize("n_crops", [1, 5, 37, 300])
-def test_split_f16_resident_weight_kernels_against_the_chunked_kernel(engine, split_engine, n_crops):
-    """Layer2's five stride-1 64 -> 64 convolutions with the weights resident in registers against conv_split_kernel<256, 64, 8, 1,
-    true> on the same tensors.  conv_c64r.hip (one wave per SIMD, one running sum over K): the same products in the same order per
-    output element - the backbone's features are equal bit for bit.  conv_c64k.hip (the default: two waves per SIMD split K and add
-    their partial sums; bias and residual enter through one wave's accumulators): fp32 rounding apart, far inside the split
-    arithmetic's own distance to fp32, and deterministic.  1 crop = 4.5 tiles of 128 pixels (fewer tiles than workgroups, a ragged
-    last tile, image borders inside a tile), 5 crops = 22.5, 37 = 166.5, 300 crops = 1350 tiles on 256 persistent workgroups
-    (5.3 tiles each: the double-buffered patches wrap, workgroups with five and with six tiles)."""
+def test_split_f16_resident_weight_kernel_against_the_chunked_kernel(engine, split_engine, n_crops):
+    """Layer2's five stride-1 64 -> 64 convolutions with the weights resident in registers (conv_c64k.hip: two waves per SIMD
+    split K and add their partial sums; bias and residual enter through one wave's accumulators) against conv_split_kernel<256, 64,
+    8, 1, true> on the same tensors: fp32 rounding apart, far inside the split arithmetic's own distance to fp32, and deterministic.
+    1 crop = 4.5 tiles of 128 pixels (fewer tiles than workgroups, a ragged last tile, image borders inside a tile), 5 crops = 22.5,
+    37 = 166.5, 300 crops = 1350 tiles on 256 persistent workgroups (5.3 tiles each: the double-buffered patches wrap, workgroups
+    with five and with six tiles)."""
     crops = _dev(synth.synthetic_crops(n_crops, seed=23 + n_crops))
     pair = split_engine.backbone(crops)
     try:
         split_engine.set_resident_weights(0)
         chunked = split_engine.backbone(crops)
-        split_engine.set_resident_weights(2)
-        single = split_engine.backbone(crops)
     finally:
         split_engine.set_resident_weights(1)
     assert torch.isfinite(pair).all()
-    assert torch.equal(single, chunked)
     assert torch.equal(split_engine.backbone(crops), pair)           # deterministic
     fp32 = engine.backbone(crops)
     scale = max(1.0, fp32.abs().max().item())
@@ -193,6 +189,41 @@ def test_split_f16_power_of_two_rescale_invariance(engine, split_engine, k):
         scale = max(1.0, base32.abs().max().item())
         assert (got - base32).abs().max().item() < 1e-5 * scale            # split vs fp32: as for the unscaled network
         assert torch.equal(got, base_split)                                # and the same bits as the unscaled split run
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("spread", [8, 12, 16, 24])
+def test_split_f16_per_channel_rescale_invariance(engine, split_engine, spread):
+    """The split arithmetic keeps ONE power-of-two scale per activation tensor and one per weight tensor, so a channel far below
+    its tensor's largest (a near-dead BatchNorm channel whose consumer weights compensate: the same fp32 function) would lose its
+    second fp16 piece.  ut_create therefore brings every inner and trunk channel to a canonical power-of-two scale before packing
+    (exact; csrc/ut_api.hip::fold_backbone).  Here every inner AND trunk channel of the backbone is rescaled by its own random
+    2^k, k in [-spread, spread] (channel spread up to 2^48): the fp32 kernels give the same bits (powers of two commute with every
+    rounding), the split kernels give the same bits as on the original network (both pack to the same tensors), and the
+    reference's own goldens hold at the path's tolerances."""
+    crops = _dev(synth.synthetic_crops(7, seed=3))
+    base32, base_split = engine.backbone(crops), split_engine.backbone(crops)
+    eng = _native.HipEngine(synth.channel_rescaled_state_dict(synth.synthetic_state_dict(0), spread, seed=100 + spread), DEV)
+    try:
+        assert torch.equal(eng.backbone(crops), base32)
+        eng.set_conv_arithmetic("split_f16_always")
+        got = eng.backbone(crops)
+        eng.poll_status()
+        assert (got - base32).abs().max().item() < 1e-5 * max(1.0, base32.abs().max().item())
+        assert torch.equal(got, base_split)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("known", [True, False])
+def test_split_f16_per_channel_rescaled_network_matches_reference_goldens(golden_dir, known):
+    """A per-channel rescaled network (spread 2^+-24) through backbone + head against the reference's own outputs."""
+    eng = _native.HipEngine(synth.channel_rescaled_state_dict(synth.synthetic_state_dict(0), 24, seed=7), DEV)
+    try:
+        eng.set_conv_arithmetic("split_f16_always")
+        test_model_matches_reference_goldens(eng, golden_dir, known)
+        eng.poll_status()
     finally:
         eng.close()
 

@@ -359,3 +359,54 @@ def test_register_resident_kernels_keep_their_register_plan(tmp_path, source):
     assert "scratch_" not in asm
     assert asm.count("v_mfma_f32_32x32x16_f16") in (108, 60)          # per wave and tile: 9 x 2 x 2 x 3, or 9 x 2 x 3 + 2 x 3
     assert re.search(r"Occupancy \[waves/SIMD\]: 2", r.stderr)
+
+
+def _parse_canonical(flat):
+    """ut_canonical_backbone_weights' layout -> (stem, [(conv1, conv2, ds | None, stride)], proj), each conv = (w OIHW, b)."""
+    pos = 0
+
+    def take(cout, cin, k):
+        nonlocal pos
+        w = flat[pos: pos + cout * cin * k * k].reshape(cout, cin, k, k); pos += w.size
+        b = flat[pos: pos + cout]; pos += cout
+        return torch.from_numpy(w.copy()), torch.from_numpy(b.copy())
+    stem = take(32, 1, 3)
+    blocks = []
+    for _p, cin, cout, stride, ds in arch.backbone_blocks():
+        c1, c2 = take(cout, cin, 3), take(cout, cout, 3)
+        blocks.append((c1, c2, take(cout, cin, 1) if ds else None, stride))
+    proj = take(72, 256, 1)
+    assert pos == flat.size
+    return stem, blocks, proj
+
+
+@pytest.mark.parametrize("spread", [8, 24])
+def test_pack_time_channel_canonicalisation_is_exact_and_invariant(spread):
+    """ut_create brings every inner and trunk channel of the backbone to a canonical power-of-two scale before packing
+    (csrc/ut_api.hip::fold_backbone; host only, so it is checked here without a GPU through ut_canonical_backbone_weights):
+    (i) checkpoints that differ by per-channel powers of two - up to 2^48 between two channels of one tensor here - pack to the
+    same tensors bit for bit, which is what makes the split-fp16 arithmetic (one scale per tensor) see the same network whatever
+    a checkpoint's per-channel scales; (ii) the packed network is the checkpoint's function (torch CPU fp32 on the folded,
+    canonicalised convolutions against the oracle's conv + batch_norm pipeline); (iii) every block's inner channel has its
+    largest conv1-row magnitude in [1, 2)."""
+    from oracle import ref_model
+    sd = synth.synthetic_state_dict(0)
+    base = _native.canonical_backbone_weights(sd)
+    for inner, trunk in ((True, False), (False, True), (True, True)):
+        other = _native.canonical_backbone_weights(synth.channel_rescaled_state_dict(sd, spread, seed=spread, inner=inner, trunk=trunk))
+        assert np.array_equal(other.view(np.uint32), base.view(np.uint32)), (inner, trunk)
+    raw = synth.channel_rescaled_state_dict(sd, spread, seed=1)
+    assert max(np.abs(raw[k]).max() / np.abs(sd[k]).max() for k in sd if k.endswith("conv2.weight")) > 2.0 ** (spread - 2)
+    stem, blocks, proj = _parse_canonical(base)
+    F = torch.nn.functional
+    crops = torch.from_numpy(synth.synthetic_crops(2, seed=5))
+    x = F.max_pool2d(F.relu(F.conv2d(crops.unsqueeze(1), stem[0], stem[1], 1, 1)), 2, 2)
+    for c1, c2, ds, stride in blocks:
+        m = torch.maximum(c1[0].abs().amax(dim=(1, 2, 3)), c1[1].abs())
+        assert (m >= 1).all() and (m < 2).all()
+        h = F.relu(F.conv2d(x, c1[0], c1[1], stride, 1))
+        h = F.conv2d(h, c2[0], c2[1], 1, 1)
+        x = F.relu(h + (F.conv2d(x, ds[0], ds[1], stride) if ds is not None else x))
+    got = F.conv2d(x, proj[0], proj[1])
+    want = ref_model.backbone(ref_model.to_torch_state_dict(sd), crops)
+    assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())

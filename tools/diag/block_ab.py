@@ -42,7 +42,7 @@ def build(name, patches, alt=None):
         open(src, "w").write(text)
     so = f"/tmp/libblockab_{name}.so"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w", "-DBLOCK_W4", *(["-DW4_STAMPS"] if STAMPS else []), "-o", so, src,
-                           W4_SRC, os.path.join(CSRC, "conv_split.hip"), os.path.join(CSRC, "conv_c64r.hip"), os.path.join(CSRC, "conv_c64k.hip"),
+                           W4_SRC, os.path.join(CSRC, "conv_split.hip"), os.path.join(CSRC, "conv_c64k.hip"),
                            os.path.join(ROOT, "tools", "diag", "block_entry.hip"), "-I", CSRC])
     return ctypes.CDLL(so)
 

@@ -49,7 +49,7 @@ def build(name, src=None, patches=()):
         open(src, "w").write(text)
     so = f"/tmp/libs2ab_{name}.so"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w", "-o", so, src,
-                           os.path.join(CSRC, "conv_split.hip"), os.path.join(CSRC, "conv_c64r.hip"), os.path.join(CSRC, "conv_c64k.hip"),
+                           os.path.join(CSRC, "conv_split.hip"), os.path.join(CSRC, "conv_c64k.hip"),
                            os.path.join(ROOT, "tools", "diag", "s2_entry.hip"), "-I", CSRC])
     return ctypes.CDLL(so)
 

@@ -83,7 +83,7 @@ def build(name, patches, flags=(), alt=None, c64=None, c64k=None):
             text = text.replace(old, new)
         src = f"/tmp/conv_split_{name}.hip"
         open(src, "w").write(text)
-    c64_src = c64 or os.path.join(CSRC, "conv_c64r.hip")
+    c64_src = c64 or os.path.join(ROOT, "tools", "diag", "conv_c64r.hip")
     so = f"/tmp/libsplitab_{name}.so"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w", *flags, "-o", so,
                            os.path.join(CSRC, "conv_igemm.hip"), os.path.join(CSRC, "conv_patch.hip"), c64_src, c64k or os.path.join(CSRC, "conv_c64k.hip"), src,

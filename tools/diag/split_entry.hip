@@ -4,6 +4,11 @@
 
 #include "ut_kernels.h"
 
+namespace ut {      // tools/diag/conv_c64r.hip (lab: the one-wave-per-SIMD predecessor of conv_c64k.hip)
+bool conv_c64r_applicable(const ConvLaunch& c);
+hipError_t launch_conv_c64r(const ConvLaunch& c, hipStream_t s);
+}
+
 static float g_unscale = 1.f;
 extern "C" int split_pack(const float* w, int cout_pad, int k_pad, uint16_t* out) {
   const float scale = ut::split_weight_scale(w, (size_t)cout_pad * k_pad);
@@ -33,7 +38,8 @@ extern "C" int conv_diag2(const float* in, const float* w, const void* w_split, 
   (void)hipMemsetAsync(cnt, 0, 4, 0);
   c.tile_counter = cnt;
   if (!mode) c.w_split = nullptr;
-  c.no_resident = mode == 2 ? 2 : mode == 3 ? 1 : 0;      // 1: conv_c64k where applicable, 2: conv_c64r, 3: the chunked kernel
+  c.no_resident = mode == 3 ? 1 : 0;      // 1: conv_c64k where applicable, 2: conv_c64r (lab), 3: the chunked kernel
+  if (mode == 2 && ut::conv_c64r_applicable(c)) return (int)ut::launch_conv_c64r(c, 0);
 #ifdef C64_STAMPS
   if (!g_dbg) { (void)hipMalloc((void**)&g_dbg, 256 * 8 * 8); (void)hipMemset(g_dbg, 0, 256 * 8 * 8); }
   c.status = g_dbg;
