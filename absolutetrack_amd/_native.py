@@ -24,7 +24,7 @@ EXPORTS = (
     "ut_resample_homography", "ut_keypoint_metrics", "ut_profile_begin", "ut_profile_end", "ut_profile_end_by_kind",
     "ut_set_index_checks", "ut_poll_status", "ut_warp_backbone", "ut_set_latency_mode", "ut_set_conv_arithmetic",
     "ut_set_backbone_lanes", "ut_status_snapshot", "ut_warp_map", "ut_set_block_fusion", "ut_set_resident_weights",
-    "ut_canonical_backbone_weights",
+    "ut_canonical_backbone_weights", "ut_set_split_scale", "ut_calibrate_split", "ut_get_split_calibration",
 )
 
 UT_MODE_KNOWN, UT_MODE_UNKNOWN = 0, 1
@@ -112,6 +112,12 @@ def load_library() -> ctypes.CDLL:
     lib.ut_set_conv_arithmetic.argtypes = [vp, i32]
     lib.ut_poll_status.restype = i32
     lib.ut_poll_status.argtypes = [vp, vp]
+    lib.ut_set_split_scale.restype = i32
+    lib.ut_set_split_scale.argtypes = [vp, i32]
+    lib.ut_calibrate_split.restype = i32
+    lib.ut_calibrate_split.argtypes = [vp, vp, i32, vp]
+    lib.ut_get_split_calibration.restype = i32
+    lib.ut_get_split_calibration.argtypes = [vp, vp]
     lib.ut_canonical_backbone_weights.restype = i32
     lib.ut_canonical_backbone_weights.argtypes = [vp, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     _lib = lib
@@ -467,6 +473,30 @@ class HipEngine:
         matrix cores from two-piece splits of both operands (fp32-level error, not the fp32 chain's bits), for calls of
         >= 2 x CUs crops (one arithmetic per call); "split_f16_always": calls of any size (tests)."""
         self._check(self.lib.ut_set_conv_arithmetic(self._h, {"fp32": 0, "split_f16": 1, "split_f16_always": 2}[mode]), "ut_set_conv_arithmetic")
+
+    def set_split_scale(self, mode: str):
+        """Split-fp16 mode: "calibrated" (default) - one fixed power-of-two activation scale per backbone tensor and handle (a
+        crop's bits do not depend on its batch, lane count or sharding; inputs beyond 32 x the calibration maximum are reported
+        by poll_status as FloatingPointError) - or "dynamic": each launch scales by the largest magnitude its producer stored in
+        this call."""
+        self._check(self.lib.ut_set_split_scale(self._h, {"calibrated": 0, "dynamic": 1}[mode]), "ut_set_split_scale")
+
+    def calibrate_split(self, crops: Optional[torch.Tensor] = None):
+        """Take the calibrated activation scales from `crops` ([n,96,96] fp32 on the device; None: the built-in synthetic set,
+        which is what a handle uses when this is never called)."""
+        if crops is None:
+            self._check(self.lib.ut_calibrate_split(self._h, None, 0, _stream(self.device)), "ut_calibrate_split")
+            return
+        crops = _need(crops, torch.float32, self.device, "crops")
+        if crops.ndim != 3 or tuple(crops.shape[1:]) != (arch.CROP, arch.CROP) or crops.shape[0] == 0:
+            raise ValueError(f"crops must be [n >= 1,{arch.CROP},{arch.CROP}], got {tuple(crops.shape)}")
+        self._check(self.lib.ut_calibrate_split(self._h, _ptr(crops), crops.shape[0], _stream(self.device)), "ut_calibrate_split")
+
+    def split_calibration(self) -> np.ndarray:
+        """The 25 calibrated scale words (stem output, then every block's inner tensor and output) as float32."""
+        out = np.zeros(25, np.float32)
+        self._check(self.lib.ut_get_split_calibration(self._h, out.ctypes.data_as(ctypes.c_void_p)), "ut_get_split_calibration")
+        return out
 
     def poll_status(self):
         self._check(self.lib.ut_poll_status(self._h, _stream(self.device)), "ut_poll_status")

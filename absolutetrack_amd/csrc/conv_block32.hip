@@ -123,7 +123,7 @@ __global__ __launch_bounds__(64 * B_WAVES) void conv_block32_kernel(BlockLaunch 
   float x_scale = 1.f, x_unscale = 1.f, i_scale = 1.f, i_unscale = 1.f;
   {
     bool ok;
-    split_act_scale(p.in_max, x_scale, x_unscale, ok);
+    split_act_scale(p.in_max, p.in_obs, x_scale, x_unscale, ok);
     if (!ok && tid == 0 && blockIdx.x == 0 && p.status) atomicOr(p.status, UT_SPLIT_RANGE);
     const float xmax = ok ? __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)*p.in_max)) : 0.f;
     b_pow2_for(xmax * p.wsum1 + p.bmax1, i_scale, i_unscale);

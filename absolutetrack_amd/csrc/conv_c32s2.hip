@@ -153,7 +153,7 @@ __global__ __launch_bounds__(512, 1) void conv_c32s2_kernel(Stride2Launch p, int
   float x_scale = 1.f, x_unscale = 1.f;
   if (p.in_max) {
     bool ok;
-    split_act_scale(p.in_max, x_scale, x_unscale, ok);
+    split_act_scale(p.in_max, p.in_obs, x_scale, x_unscale, ok);
     if (!ok && tid == 0 && blockIdx.x == 0 && p.status) atomicOr(p.status, UT_SPLIT_RANGE);
   }
   const float unscale1 = p.unscale1 * x_unscale, unscale_d = p.unscale_d * x_unscale;

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_c32_patch_kernel(ConvLaunch p
   if constexpr (SPLIT) {
     if (p.in_max) {
       bool ok;
-      split_act_scale(p.in_max, x_scale, x_unscale, ok);
+      split_act_scale(p.in_max, p.in_obs, x_scale, x_unscale, ok);
       if (!ok && tid == 0 && blockIdx.x == 0 && p.status) atomicOr(p.status, UT_SPLIT_RANGE);
     }
   }

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(ConvLaunch p, int ti
   float x_scale = 1.f, x_unscale = 1.f;
   if (p.in_max) {
     bool ok;
-    split_act_scale(p.in_max, x_scale, x_unscale, ok);
+    split_act_scale(p.in_max, p.in_obs, x_scale, x_unscale, ok);
     if (!ok && tid == 0 && blockIdx.x == 0 && p.status) atomicOr(p.status, UT_SPLIT_RANGE);
   }
   const float tot_unscale = p.split_unscale * x_unscale;

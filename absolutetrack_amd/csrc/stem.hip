@@ -126,4 +126,57 @@ hipError_t launch_merge_max(unsigned* dst, const unsigned* src, hipStream_t s) {
   return hipGetLastError();
 }
 
+__global__ void raise_words_kernel(unsigned* w, int n, int add_exp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned v = w[i];
+  int e = (int)(v >> 23) & 255;
+  if (v == 0u || e == 255) return;
+  e = e + add_exp > 254 ? 254 : e + add_exp;
+  w[i] = ((unsigned)e << 23) | (v & 0x7FFFFFu);
+}
+
+hipError_t launch_raise_words(unsigned* words, int n, int add_exp, hipStream_t s) {
+  hipLaunchKernelGGL(raise_words_kernel, dim3((n + 63) / 64), dim3(64), 0, s, words, n, add_exp);
+  return hipGetLastError();
+}
+
+// Built-in calibration crops.  Crop i is one of four families (i & 3): 0 full-range noise, 1 low-contrast noise around a grey
+// level, 2 a linear ramp plus noise, 3 bright Gaussian blobs on a dark ground plus noise (an IR hand image's statistics);
+// amplitude and geometry vary with i >> 2.  Values are grey levels k / 255 like lib/tracker/tracker.py:332 produces.
+__device__ __forceinline__ unsigned calib_hash(unsigned x) {
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+__global__ __launch_bounds__(256) void calibration_crops_kernel(float* out, int n) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * CROP * CROP) return;
+  const int i = idx / (CROP * CROP), px = idx % (CROP * CROP), y = px / CROP, x = px % CROP;
+  const unsigned hp = calib_hash((unsigned)idx * 2654435761u + 12345u);
+  const float u = (float)(hp >> 8) * (1.0f / 16777216.0f);                       // pixel noise in [0, 1)
+  const unsigned hc = calib_hash((unsigned)i * 40503u + 977u);
+  const float a = (float)(hc & 255) * (1.0f / 255.0f), b = (float)((hc >> 8) & 255) * (1.0f / 255.0f),
+              c = (float)((hc >> 16) & 255) * (1.0f / 255.0f);
+  const float fx = (float)x * (1.0f / CROP), fy = (float)y * (1.0f / CROP);
+  float v;
+  switch (i & 3) {
+    case 0: v = u; break;
+    case 1: v = 0.1f + 0.8f * a + (0.02f + 0.2f * b) * (u - 0.5f); break;
+    case 2: v = a * fx + b * fy + 0.3f * c * u; break;
+    default: {
+      const float dx0 = fx - a, dy0 = fy - b, dx1 = fx - c, dy1 = fy - a;
+      const float s0 = 0.05f + 0.2f * c, s1 = 0.05f + 0.2f * b;
+      v = 0.05f + 0.9f * __expf(-(dx0 * dx0 + dy0 * dy0) / (2.f * s0 * s0)) + 0.6f * __expf(-(dx1 * dx1 + dy1 * dy1) / (2.f * s1 * s1)) + 0.1f * u;
+    }
+  }
+  v = fminf(fmaxf(v, 0.f), 1.f);
+  out[idx] = floorf(v * 255.f + 0.5f) / 255.0f;
+}
+
+hipError_t launch_calibration_crops(float* crops, int n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(calibration_crops_kernel, dim3((n * CROP * CROP + 255) / 256), dim3(256), 0, s, crops, n);
+  return hipGetLastError();
+}
+
 }  // namespace ut

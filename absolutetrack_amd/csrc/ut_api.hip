@@ -86,6 +86,13 @@ struct ut_context {
   // [kMaxCounters + i] the bits of the largest magnitude that launch stored (the activation scale of a split-fp16 consumer)
   unsigned* counters = nullptr;
   int counter_next = 0;
+  // split-fp16 activation scales.  Tensor ids: 0 the stem's output, 1 + 2b the output of block b's first convolution, 2 + 2b
+  // block b's output (b = 0 .. 11).  calib[t]: the bits of 2^kCalibHeadroom x the largest magnitude of tensor t over the
+  // calibration crops (device words behind the per-launch words; never zeroed by begin_call).
+  unsigned* calib = nullptr;
+  int scale_mode = UT_SPLIT_SCALE_CALIBRATED;
+  bool calibrated = false;
+  bool calibrating = false;         // the running backbone call is a calibration pass: dynamic scales, maxima merged into calib
   unsigned word_gen = 0;            // bumped by every zeroing of the words: a max word kept across launches is stale after it
   bool block_fusion = true;         // split-fp16 mode: layer1's BasicBlocks as one launch each (ut_set_block_fusion)
   int resident_weights = 1;         // split-fp16 mode: layer2's 64 -> 64 convolutions: 1 conv_c64k, 0 the chunked kernel (ut_set_resident_weights)
@@ -185,7 +192,8 @@ int stateless_status(int* device_out, DevStatus* out) {
 
 const char* status_message(int bits) {
   if (bits & ut::UT_SPLIT_RANGE)
-    return "range check: an activation entering a split-fp16 convolution is an infinity or a NaN (the layer has no finite scale)";
+    return "range check: an activation entering a split-fp16 convolution is an infinity or a NaN, or lies beyond the calibrated range "
+           "of its layer (32 x the calibration maximum; ut_calibrate_split with representative crops, or UT_SPLIT_SCALE_DYNAMIC)";
   if (bits & ut::UT_BAD_SRC_INDEX) return "index check: src_index outside [0, n_src_images)";
   if (bits & ut::UT_BAD_SAMPLE_RANGE) return "index check: sample_range rows must select 1 or 2 crops inside [0, n_crops]";
   if (bits & ut::UT_BAD_MEMORY_IDX) return "index check: memory_idx outside [0, n_slots)";
@@ -582,6 +590,9 @@ int ensure_slots(ut_handle h, int slots, hipStream_t s) {
 }
 
 constexpr int kMaxCounters = 4096;
+constexpr int kScaleTensors = 25;
+constexpr int kCalibHeadroom = 4;      // calibrated scale words hold 2^4 x the calibration maximum: inputs up to 32 x that maximum
+                                       // (the scale leaves another factor 2 under fp16's 65504) are inside the split's range
 
 // zero the per-launch words (tile queues, output maxima) used by the launches of one API call (stream ordered)
 int begin_call(ut_handle h, hipStream_t s) {
@@ -601,10 +612,28 @@ int next_launch_word(ut_handle h, hipStream_t s, int* idx) {
   return UT_OK;
 }
 
-// in_max: the max word of the launch that produced `in` (null: unknown - the launch then stays on the fp32 instruction);
+// The scale word a split-fp16 consumer of tensor `tid` reads, and the word it guards against: calibrated mode - the handle's
+// calibrated word, guarded by the word the producer left in this call (may be null); dynamic mode and calibration passes - the
+// producer's word itself (null: no scale, the launch stays on the fp32 instruction).
+struct ScaleRef { const unsigned* word = nullptr; const unsigned* obs = nullptr; };
+ScaleRef scale_for(ut_handle h, int tid, const unsigned* producer_word) {
+  ScaleRef r;
+  if (!h->call_split || h->latency_mode || tid < 0 || tid >= kScaleTensors) return r;
+  if (h->calibrating || h->scale_mode == UT_SPLIT_SCALE_DYNAMIC) r.word = producer_word;
+  else { r.word = h->calib + tid; r.obs = producer_word; }
+  return r;
+}
+// calibration pass: fold the producer's word of tensor `tid` into its calibrated word
+int note_calibration(ut_handle h, int tid, const unsigned* producer_word, hipStream_t s) {
+  if (h->calibrating && producer_word && tid >= 0 && tid < kScaleTensors) HIPCHK(h, ut::launch_merge_max(h->calib + tid, producer_word, s));
+  return UT_OK;
+}
+
+// in_max: the max word of the launch that produced `in` (null: unknown); in_tid: the tensor id of `in` (< 0: not a tensor of the
+// split-fp16 path - the launch stays on the fp32 instruction);
 // *out_max (optional): receives this launch's max word when it ran a kernel that leaves one, else null
 int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, float* out, int n_img, int H, int W,
-             bool relu, bool nchw, hipStream_t s, const unsigned* in_max = nullptr, unsigned** out_max = nullptr) {
+             bool relu, bool nchw, hipStream_t s, const unsigned* in_max = nullptr, unsigned** out_max = nullptr, int in_tid = -1) {
   if (out_max) *out_max = nullptr;
   ut::ConvLaunch c{};
   c.in = in; c.w = cw.w; c.bias = cw.bias; c.res = res; c.out = out;
@@ -655,14 +684,18 @@ int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, fl
   }
   // split-fp16 arithmetic: decided once per backbone call (run_backbone), for every eligible layer of the call whose
   // producer left a max word; everything else - the head, and every launch in latency mode - stays on the fp32 instruction
-  c.w_split = h->call_split && in_max && !h->latency_mode ? cw.w_split : nullptr;
+  const ScaleRef sr = scale_for(h, in_tid, in_max);
+  c.w_split = sr.word ? cw.w_split : nullptr;
   c.split_unscale = cw.split_unscale;
   c.status = h->status;
-  c.in_max = in_max;
+  c.in_max = sr.word;
+  c.in_obs = sr.obs;
   pe.kind = c.w_split && (ut::conv_split_applicable(c) || ut::conv_patch_applicable(c)) ? 1 : 0;
   if (pe.kind) {
     c.out_max = h->counters + kMaxCounters + word;
     if (out_max) *out_max = c.out_max;
+    int rc1 = note_calibration(h, in_tid, in_max, s);
+    if (rc1) return rc1;
   }
   if (c.w_split && ut::conv_split_applicable(c)) HIPCHK(h, ut::launch_conv_split(c, s));
   else HIPCHK(h, ut::launch_conv_igemm(c, s));
@@ -674,26 +707,36 @@ int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, fl
 }
 
 // relu(bn2(conv2(relu(bn1(conv1 x)))) + (downsample(x) | x))   lib/models/backbone_resnet.py:56-72
-// x_max: the max word of x's producer (or null); *y_max (optional): the word of the block's output
+// x_max: the max word of x's producer (or null); *y_max (optional): the word of the block's output;
+// blk: the block's index in the backbone (x is tensor 2 blk, conv1's output 2 blk + 1), < 0 for the head's blocks
 int run_block(ut_handle h, const Block& b, const float* x, float* tmp, float* dsbuf, float* y, int n_img, int H,
-              int W, hipStream_t s, const unsigned* x_max = nullptr, unsigned** y_max = nullptr) {
+              int W, hipStream_t s, const unsigned* x_max = nullptr, unsigned** y_max = nullptr, int blk = -1) {
   int rc;
   if (y_max) *y_max = nullptr;
+  // the words of one block (at most three launches) come from one zeroing: a word handed from conv1 to conv2 is never recycled
+  // between the two (x's own word is gone after a recycle: its consumers then run unguarded / on the fp32 instruction)
+  if (h->counter_next + 8 > kMaxCounters) {
+    if ((rc = begin_call(h, s))) return rc;
+    x_max = nullptr;
+  }
+  const int x_tid = blk >= 0 ? 2 * blk : -1, mid_tid = blk >= 0 ? 2 * blk + 1 : -1;
+  const ScaleRef xs = scale_for(h, x_tid, x_max);
   // layer1 in split-fp16 mode: the whole block in one launch, the intermediate stays in LDS (conv_block32.hip)
-  if (h->call_split && h->block_fusion && x_max && !h->latency_mode && !b.has_ds && b.conv1.w_split && b.conv2.w_split && b.conv1.stride == 1 &&
+  if (h->block_fusion && xs.word && !b.has_ds && b.conv1.w_split && b.conv2.w_split && b.conv1.stride == 1 &&
       b.conv1.cin_pad == 32 && b.conv1.cout_store == 32 && b.conv2.cout_store == 32) {
     ut::BlockLaunch bl{};
     bl.in = x; bl.out = y; bl.w1_split = b.conv1.w_split; bl.w2_split = b.conv2.w_split;
     bl.unscale_w1 = b.conv1.split_unscale; bl.unscale_w2 = b.conv2.split_unscale;
     bl.bias1 = b.conv1.bias; bl.bias2 = b.conv2.bias;
     bl.wsum1 = b.conv1.wsum_rows; bl.bmax1 = b.conv1.bias_max;
-    bl.in_max = x_max; bl.status = h->status;
+    bl.in_max = xs.word; bl.in_obs = xs.obs; bl.status = h->status;
     bl.n_img = n_img; bl.H = H; bl.W = W; bl.device = h->device; bl.num_cu = h->num_cu;
     if (ut::conv_block32_applicable((bl.tile_counter = h->counters, bl))) {
       const unsigned gen = h->word_gen;
       int word = 0;
       if ((rc = next_launch_word(h, s, &word))) return rc;
-      if (gen == h->word_gen) {          // (a recycle in mid-call zeroed x's word: fall through to the two-launch path)
+      if (gen == h->word_gen) {          // (never a recycle here: the block's words were reserved above)
+        if ((rc = note_calibration(h, x_tid, x_max, s))) return rc;
         bl.tile_counter = h->counters + word;
         bl.out_max = h->counters + kMaxCounters + word;
         ProfEvent pe{};
@@ -712,23 +755,23 @@ int run_block(ut_handle h, const Block& b, const float* x, float* tmp, float* ds
         if (y_max) *y_max = bl.out_max;
         return UT_OK;
       }
-      x_max = nullptr;
     }
   }
   // layer2's entry in split-fp16 mode: the stride-2 3x3 and the 1x1 shortcut from one pass over x (conv_c32s2.hip)
-  if (h->call_split && h->block_fusion && x_max && !h->latency_mode && b.has_ds && b.conv1.w_split && b.ds.w_split && b.conv2.w_split &&
+  if (h->block_fusion && xs.word && b.has_ds && b.conv1.w_split && b.ds.w_split && b.conv2.w_split &&
       b.conv1.stride == 2 && b.conv1.cin_pad == 32 && b.conv1.cout_store == 64 && b.ds.cout_store == 64 && dsbuf) {
     ut::Stride2Launch sl{};
     sl.in = x; sl.out1 = tmp; sl.out2 = dsbuf; sl.w1_split = b.conv1.w_split; sl.wd_split = b.ds.w_split;
     sl.unscale1 = b.conv1.split_unscale; sl.unscale_d = b.ds.split_unscale;
     sl.bias1 = b.conv1.bias; sl.bias_d = b.ds.bias;
-    sl.in_max = x_max; sl.status = h->status;
+    sl.in_max = xs.word; sl.in_obs = xs.obs; sl.status = h->status;
     sl.n_img = n_img; sl.H = H; sl.W = W; sl.device = h->device; sl.num_cu = h->num_cu;
     if (ut::conv_c32s2_applicable(sl)) {
       const unsigned gen = h->word_gen;
       int word = 0;
       if ((rc = next_launch_word(h, s, &word))) return rc;
-      if (gen == h->word_gen) {          // (a recycle in mid-call zeroed x's word: fall through to the separate launches)
+      if (gen == h->word_gen) {
+        if ((rc = note_calibration(h, x_tid, x_max, s))) return rc;
         sl.out1_max = h->counters + kMaxCounters + word;
         ProfEvent pe{};
         if (h->profiling) {
@@ -743,20 +786,19 @@ int run_block(ut_handle h, const Block& b, const float* x, float* tmp, float* ds
           HIPCHK(h, hipEventRecord(pe.b, s));
           h->prof.push_back(pe);
         }
-        return run_conv(h, b.conv2, tmp, dsbuf, y, n_img, H / 2, W / 2, true, false, s, sl.out1_max, y_max);
+        return run_conv(h, b.conv2, tmp, dsbuf, y, n_img, H / 2, W / 2, true, false, s, sl.out1_max, y_max, mid_tid);
       }
-      x_max = nullptr;
     }
   }
   unsigned* tmp_max = nullptr;
-  if ((rc = run_conv(h, b.conv1, x, nullptr, tmp, n_img, H, W, true, false, s, x_max, &tmp_max))) return rc;
+  if ((rc = run_conv(h, b.conv1, x, nullptr, tmp, n_img, H, W, true, false, s, x_max, &tmp_max, x_tid))) return rc;
   const int Ho = (H + 2 - 3) / b.conv1.stride + 1, Wo = (W + 2 - 3) / b.conv1.stride + 1;
   const float* res = x;
   if (b.has_ds) {
     if ((rc = run_conv(h, b.ds, x, nullptr, dsbuf, n_img, H, W, false, false, s))) return rc;
     res = dsbuf;
   }
-  return run_conv(h, b.conv2, tmp, res, y, n_img, Ho, Wo, true, false, s, tmp_max, y_max);
+  return run_conv(h, b.conv2, tmp, res, y, n_img, Ho, Wo, true, false, s, tmp_max, y_max, mid_tid);
 }
 
 }  // namespace
@@ -805,7 +847,10 @@ int ut_create(int device, const float* blob, size_t n_floats, ut_handle* out) {
   Cursor c{blob, n_floats};
   int rc = UT_OK;
   do {
-    { float* cnt = nullptr; if ((rc = dev_alloc(h, &cnt, 2 * kMaxCounters))) break; h->counters = (unsigned*)cnt; }
+    { float* cnt = nullptr; if ((rc = dev_alloc(h, &cnt, 2 * kMaxCounters + 32))) break; h->counters = (unsigned*)cnt;
+      h->calib = h->counters + 2 * kMaxCounters;
+      hipError_t e1 = hipMemset(h->calib, 0, 32 * sizeof(unsigned));
+      if (e1 != hipSuccess) { rc = fail(h, UT_E_HIP, "calibration words", e1); break; } }
     { float* st = nullptr; if ((rc = dev_alloc(h, &st, 2))) break; h->status = (int*)st;
       hipError_t e2 = hipMemset(h->status, 0, 2 * sizeof(int));
       if (e2 == hipSuccess) e2 = hipHostMalloc((void**)&h->status_host, 2 * sizeof(int), hipHostMallocDefault);
@@ -972,7 +1017,7 @@ static int backbone_pass(ut_handle h, const float* crops, const uint8_t* crops_u
     int hw = 48;
     for (int b = 0; b < 5; ++b) {
       float* dst = b == 4 ? h->bufL2 + a24 : y;
-      if ((rc = run_block(h, h->bb[b], x, h->bufH + a48, h->bufD + a24, dst, n, hw, hw, st, xm, &xm))) return rc;
+      if ((rc = run_block(h, h->bb[b], x, h->bufH + a48, h->bufD + a24, dst, n, hw, hw, st, xm, &xm, b))) return rc;
       hw = (hw + 2 - 3) / h->bb[b].conv1.stride + 1;
       float* t = x; x = y; y = t;
     }
@@ -981,7 +1026,7 @@ static int backbone_pass(ut_handle h, const float* crops, const uint8_t* crops_u
   float *y = h->bufP + a12, *other = h->bufQ + a12;
   int hw = 24;
   for (int b = 5; b < 12; ++b) {
-    if ((rc = run_block(h, h->bb[b], x, h->bufBH + a12, h->bufBD + a12, y, n, hw, hw, st, xm, &xm))) return rc;
+    if ((rc = run_block(h, h->bb[b], x, h->bufBH + a12, h->bufBD + a12, y, n, hw, hw, st, xm, &xm, b))) return rc;
     hw = (hw + 2 - 3) / h->bb[b].conv1.stride + 1;
     x = y;
     float* t = y; y = other; other = t;
@@ -1045,7 +1090,7 @@ static int run_backbone(ut_handle h, const float* crops, const uint8_t* crops_u8
       int hw = 48;
       for (int b = 0; b < 5; ++b) {
         float* dst = b == 4 ? h->bufL2 + (size_t)done * 24 * 24 * 64 : y;
-        if ((rc = run_block(h, h->bb[b], x, h->bufH, h->bufD, dst, n, hw, hw, s, xm, &xm))) return rc;
+        if ((rc = run_block(h, h->bb[b], x, h->bufH, h->bufD, dst, n, hw, hw, s, xm, &xm, b))) return rc;
         hw = (hw + 2 - 3) / h->bb[b].conv1.stride + 1;
         float* t = x; x = y; y = t;
       }
@@ -1059,7 +1104,7 @@ static int run_backbone(ut_handle h, const float* crops, const uint8_t* crops_u8
     int hw = 24;
     unsigned* xm = l2_gen == h->word_gen ? l2_max : nullptr;
     for (int b = 5; b < 12; ++b) {
-      if ((rc = run_block(h, h->bb[b], x, h->bufBH, h->bufBD, y, nb, hw, hw, s, xm, &xm))) return rc;
+      if ((rc = run_block(h, h->bb[b], x, h->bufBH, h->bufBD, y, nb, hw, hw, s, xm, &xm, b))) return rc;
       hw = (hw + 2 - 3) / h->bb[b].conv1.stride + 1;
       x = y;
       float* t = y; y = other; other = t;
@@ -1068,6 +1113,69 @@ static int run_backbone(ut_handle h, const float* crops, const uint8_t* crops_u8
     if ((rc = run_conv(h, h->proj, x, nullptr, feat + (size_t)base * 72 * 36, nb, 6, 6, false, true, s))) return rc;
   }
   return UT_OK;
+}
+
+// Calibration of the split-fp16 activation scales: `crops` (device fp32 [n,96,96]) through the backbone with the per-launch
+// (dynamic) scales, every tensor's largest magnitude folded into its calibrated word, then raised by 2^kCalibHeadroom.
+// Synchronous; the status words are left as they were (a calibration pass reports nothing: a non-finite activation ends up in
+// the calibrated word and is flagged by the calls that use it).
+static int calibrate_split(ut_handle h, const float* crops, int n, hipStream_t s) {
+  float* feat = nullptr;
+  int rc = dev_alloc(h, &feat, (size_t)n * 72 * 36);
+  if (rc) return rc;
+  int saved[2] = {0, 0};
+  HIPCHK(h, hipStreamSynchronize(s));
+  HIPCHK(h, hipMemcpy(saved, h->status, sizeof saved, hipMemcpyDeviceToHost));
+  const int arith = h->conv_arith, lanes = h->lanes;
+  const bool prof = h->profiling;
+  h->conv_arith = UT_CONV_SPLIT_F16_ALWAYS; h->lanes = 1; h->profiling = false; h->calibrating = true;
+  rc = (int)ut::launch_zero_words(h->calib, 32, s) != 0 ? fail(h, UT_E_HIP, "launch_zero_words") : run_backbone(h, crops, nullptr, n, feat, s);
+  h->conv_arith = arith; h->lanes = lanes; h->profiling = prof; h->calibrating = false;
+  if (!rc) {
+    HIPCHK(h, ut::launch_raise_words(h->calib, kScaleTensors, kCalibHeadroom, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    HIPCHK(h, hipMemcpy(h->status, saved, sizeof saved, hipMemcpyHostToDevice));
+    h->calibrated = true;
+  }
+  (void)hipStreamSynchronize(s);
+  dev_free(h, feat);
+  return rc;
+}
+
+constexpr int kBuiltinCalibCrops = 64;
+
+static int calibrate_builtin(ut_handle h) {
+  float* crops = nullptr;
+  int rc = dev_alloc(h, &crops, (size_t)kBuiltinCalibCrops * 96 * 96);
+  if (rc) return rc;
+  hipError_t e = ut::launch_calibration_crops(crops, kBuiltinCalibCrops, 0);
+  rc = e != hipSuccess ? fail(h, UT_E_HIP, "launch_calibration_crops", e) : calibrate_split(h, crops, kBuiltinCalibCrops, 0);
+  (void)hipDeviceSynchronize();
+  dev_free(h, crops);
+  return rc;
+}
+
+int ut_calibrate_split(ut_handle h, const float* crops, int n_crops, void* stream) {
+  if (!h) return UT_E_INVALID;
+  if (n_crops < 0 || (n_crops > 0 && !crops)) return fail(h, UT_E_INVALID, "ut_calibrate_split: bad argument");
+  ON_DEVICE_OF(h);
+  return n_crops == 0 ? calibrate_builtin(h) : calibrate_split(h, crops, n_crops, (hipStream_t)stream);
+}
+
+int ut_set_split_scale(ut_handle h, int mode) {
+  if (!h || (mode != UT_SPLIT_SCALE_CALIBRATED && mode != UT_SPLIT_SCALE_DYNAMIC)) return fail(h, UT_E_INVALID, "ut_set_split_scale: bad argument");
+  ON_DEVICE_OF(h);
+  h->scale_mode = mode;
+  if (mode == UT_SPLIT_SCALE_CALIBRATED && h->conv_arith != UT_CONV_FP32 && !h->calibrated) return calibrate_builtin(h);
+  return UT_OK;
+}
+
+int ut_get_split_calibration(ut_handle h, float* out25) {
+  if (!h || !out25) return fail(h, UT_E_INVALID, "ut_get_split_calibration: null argument");
+  ON_DEVICE_OF(h);
+  HIPCHK(h, hipDeviceSynchronize());
+  HIPCHK(h, hipMemcpy(out25, h->calib, kScaleTensors * sizeof(float), hipMemcpyDeviceToHost));
+  return h->calibrated ? UT_OK : 1;
 }
 
 int ut_backbone(ut_handle h, const float* crops, int n_crops, float* feat, void* stream) {
@@ -1296,6 +1404,10 @@ int ut_set_backbone_lanes(ut_handle h, int lanes) {
 int ut_set_conv_arithmetic(ut_handle h, int mode) {
   if (!h || (mode != UT_CONV_FP32 && mode != UT_CONV_SPLIT_F16 && mode != UT_CONV_SPLIT_F16_ALWAYS)) return fail(h, UT_E_INVALID, "ut_set_conv_arithmetic: bad argument");
   h->conv_arith = mode;
+  if (mode != UT_CONV_FP32 && h->scale_mode == UT_SPLIT_SCALE_CALIBRATED && !h->calibrated) {
+    ON_DEVICE_OF(h);
+    return calibrate_builtin(h);
+  }
   return UT_OK;
 }
 

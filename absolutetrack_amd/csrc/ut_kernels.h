@@ -18,8 +18,11 @@ struct ConvLaunch {
   const void* w_split; // optional: the two fp16 planes of (w * scale) in fragment order (conv_split.hip), or null
   float split_unscale; // 1 / scale of w_split
   int* status;         // split kernels: sticky status word, UT_SPLIT_RANGE is set when the input holds an infinity or a NaN
-  const unsigned* in_max;   // split kernels: device word with the bits of max |in| (written by the kernel that produced `in`,
-                            // see publish_abs_max): the power-of-two activation scale of the split comes from it
+  const unsigned* in_max;   // split kernels: device word with the bits of the magnitude the activation scale is taken from (see
+                            // split_act_scale): the handle's calibrated word of this tensor, or the word the producing kernel
+                            // left in this call (publish_abs_max)
+  const unsigned* in_obs;   // optional, with a calibrated in_max: the word the producer left in THIS call - an input beyond the
+                            // calibrated range sets UT_SPLIT_RANGE
   unsigned* out_max;        // optional device word (zero before the launch): receives the bits of max |out|
   const float* bias;   // [cout_pad]
   const float* res;    // optional residual, same layout as out
@@ -59,7 +62,8 @@ struct Stride2Launch {
   float unscale1, unscale_d;      // 1 / (their weight scales)
   const float* bias1;
   const float* bias_d;
-  const unsigned* in_max;   // device word of max |in| (its producer's)
+  const unsigned* in_max;   // scale word of `in` (see ConvLaunch::in_max / in_obs)
+  const unsigned* in_obs;
   unsigned* out1_max;       // device word (zero before the launch): receives the bits of max |out1|
   int* status;
   int n_img, H, W;
@@ -84,7 +88,8 @@ struct BlockLaunch {
   const float* bias2;
   float wsum1;              // max over output channels of sum_k |w1| (folded): bounds the intermediate with max|in| and bmax1
   float bmax1;              // max |bias1|
-  const unsigned* in_max;   // max word of `in` (never null)
+  const unsigned* in_max;   // scale word of `in` (never null; see ConvLaunch::in_max / in_obs)
+  const unsigned* in_obs;
   unsigned* out_max;        // optional: receives the bits of max |out|
   int* status;
   unsigned* tile_counter;
@@ -99,6 +104,11 @@ hipError_t launch_conv_block32(const BlockLaunch& b, hipStream_t s);
 hipError_t launch_zero_words(void* p, size_t n_words, hipStream_t s);
 // *dst = max(*dst, *src) on two max words (one thread): the activation of several passes read by one consumer
 hipError_t launch_merge_max(unsigned* dst, const unsigned* src, hipStream_t s);
+// calibration: every non-zero finite word (the bits of a positive float) times 2^add_exp, exponent clamped below infinity
+hipError_t launch_raise_words(unsigned* words, int n, int add_exp, hipStream_t s);
+// n fp32 crops [n,96,96] of grey levels k / 255: the built-in calibration set of the split-fp16 activation scales (noise at
+// several contrasts, gradients, bright blobs on a dark ground; counter-based, the same on every device)
+hipError_t launch_calibration_crops(float* crops, int n, hipStream_t s);
 // 3x3 stride-1 32->32 channel convs with the halo patch resident in LDS (conv_patch.hip)
 bool conv_patch_applicable(const ConvLaunch& c);
 hipError_t launch_conv_patch(const ConvLaunch& c, hipStream_t s);
@@ -161,8 +171,11 @@ __device__ __forceinline__ void publish_abs_max(unsigned* word, unsigned lane_bi
     atomicMax(word, lane_bits);
 }
 
-// scale = 2^k, unscale = 2^-k; ok = false when the word holds an infinity / a NaN (scale 1 then)
-__device__ __forceinline__ void split_act_scale(const unsigned* in_max, float& scale, float& unscale, bool& ok) {
+// scale = 2^k, unscale = 2^-k; ok = false when the word holds an infinity / a NaN (scale 1 then).
+// in_obs (optional): the largest magnitude the producer actually stored in this call, when in_max is a calibrated word: the
+// first piece of x * 2^k stays finite while x * 2^k < 2^16, i.e. while x's exponent is at most one above the word's;
+// beyond that (or a non-finite value) ok = false.
+__device__ __forceinline__ void split_act_scale(const unsigned* in_max, const unsigned* in_obs, float& scale, float& unscale, bool& ok) {
   const unsigned bits = (unsigned)__builtin_amdgcn_readfirstlane((int)*in_max);
   const int e = (int)(bits >> 23);
   ok = e != 255;
@@ -170,6 +183,10 @@ __device__ __forceinline__ void split_act_scale(const unsigned* in_max, float& s
   k = k > 100 ? 100 : k < -100 ? -100 : k;
   scale = __uint_as_float((unsigned)(127 + k) << 23);
   unscale = __uint_as_float((unsigned)(127 - k) << 23);
+  if (in_obs) {
+    const int eo = (int)((unsigned)__builtin_amdgcn_readfirstlane((int)*in_obs) >> 23);
+    if (eo == 255 || eo + k > 142) ok = false;      // 2^(eo - 127) * 2^k >= 2^16
+  }
 }
 #endif
 

@@ -98,7 +98,8 @@ int ut_status_snapshot(ut_handle h, int32_t* dst, void* stream);
 /* 1 (default) or 2: with 2, a ut_backbone / ut_warp_backbone call of >= 1024 crops that fits one workspace pass runs as
  * two half-batches on two internal streams (joined to the caller's stream before the call's work is visible to it), so
  * that the idle tail of one half's launches is filled by the other half's.  Same kernels on the same crops: results
- * are bit-identical.  Not applied between ut_profile_begin / ut_profile_end. */
+ * are bit-identical (UT_CONV_FP32, and split-fp16 with calibrated scales; with UT_SPLIT_SCALE_DYNAMIC each half takes its own
+ * scales).  Not applied between ut_profile_begin / ut_profile_end. */
 int ut_set_backbone_lanes(ut_handle h, int lanes);
 
 /* Arithmetic of the 3x3 convolutions of the backbone (all 24 of them: layer1 .. layer4; lib/models/backbone_resnet.py:56-72).
@@ -107,23 +108,50 @@ int ut_set_backbone_lanes(ut_handle h, int lanes);
  *                      piece products per k on v_mfma_f32_32x32x16_f16, fp32 accumulation: the terms dropped are ~2^-22
  *                      of a product, so the result carries fp32-level rounding error (not the fp32 chain's bits: outputs
  *                      agree with UT_CONV_FP32 to ~1e-6 relative) at up to 5.3x the matrix rate.
- *                      Range: none to respect.  Before the split both operands are multiplied by exact powers of two - the
- *                      weights per layer on the host, the activations per launch by the power of two that puts the layer's
- *                      largest activation in [2^14, 2^15), read from a device word the producing kernel leaves (no host
- *                      synchronisation) - and the result by the inverse.  Activations 2^-16 or 2^+16 of another network's
- *                      give the same bits, as with fp32; values below 2^-18 of their layer's largest keep an absolute error
- *                      of 2^-40 of that largest.  Only an infinity or a NaN among a layer's inputs has no scale: it sets a
- *                      sticky status bit that the next status read (ut_poll_status, or any call that reads the index checks
- *                      in UT_CHECK_SYNC mode) returns as UT_E_INVALID "range check: ...".
+ *                      Range and scales.  Both operands are multiplied by exact powers of two before the split and the result
+ *                      by the inverse: the weights by one power of two per layer, the activations by one per tensor - the
+ *                      power that puts the tensor's scale word in [2^14, 2^15).  What that takes care of, and what it does not:
+ *                      - a tensor's overall magnitude: any.  Networks whose activations are 2^-40 .. 2^+40 of another's give the
+ *                        same bits, as with fp32;
+ *                      - per-CHANNEL magnitudes: any.  ut_create packs every inner and trunk channel of the backbone at a
+ *                        canonical power-of-two scale (see ut_canonical_backbone_weights), so a checkpoint's per-channel scale
+ *                        freedom (near-dead BatchNorm channels with compensating consumer weights) never reaches the kernels;
+ *                      - inside a packed tensor, a value more than 2^18 below the scale word (a weight that far below its layer's
+ *                        largest) loses its second piece: it keeps an absolute error of 2^-40 of the scale word, where fp32
+ *                        would keep 2^-24 of the value.  After canonicalisation such values belong to channels (weights) whose
+ *                        contribution to the layer's output is below fp32's own rounding of that output;
+ *                      - an infinity or a NaN has no scale, and (calibrated scales) an activation of 32 x the calibration maximum
+ *                        or more would saturate the first piece: both set a sticky status bit that the next status read
+ *                        (ut_poll_status, or any call that reads the index checks in UT_CHECK_SYNC mode) returns as
+ *                        UT_E_INVALID "range check: ...".  Results of that call are then not to be used.
+ *                      Where a tensor's scale word comes from: ut_set_split_scale.
  *                      The mode is chosen once per ut_backbone / ut_warp_backbone call, for every 3x3 convolution of it:
  *                      split for calls of >= 2 x (compute units) crops (512 on MI355X: their 256-row tiles then fill the
- *                      chip down to the 6x6 maps), exact fp32 below.  The activation scale is taken over the whole
- *                      launch, so in this mode a crop's low-order bits can depend on its batch (at the 1e-7 level).
+ *                      chip down to the 6x6 maps), exact fp32 below.
  *  UT_CONV_SPLIT_F16_ALWAYS  the same for calls of any size (slower on small ones: for tests).
  * The stem, the 1x1 shortcut convolutions, the projection, the head, and every launch in latency mode stay on the fp32
  * instruction in every mode. */
 enum { UT_CONV_FP32 = 0, UT_CONV_SPLIT_F16 = 1, UT_CONV_SPLIT_F16_ALWAYS = 2 };
 int ut_set_conv_arithmetic(ut_handle h, int mode);
+
+/* Where the split-fp16 kernels take a tensor's power-of-two activation scale from.
+ *  UT_SPLIT_SCALE_CALIBRATED (default)  one scale word per activation tensor of the backbone (25: the stem's output, every
+ *      block's inner tensor and output), fixed per handle: 2^4 x the tensor's largest magnitude over a calibration set.  A crop's
+ *      result then does not depend on what else is in its batch: any batch size, pass size (ut_set_backbone_chunk), lane count or
+ *      sharding of a frame set over ranks gives the same bits, as in UT_CONV_FP32 mode.  The calibration set is built in (64
+ *      synthetic crops - noise at several contrasts, ramps, bright blobs on a dark ground - generated on the device, the same on
+ *      every rank; run when split mode is first selected) or the caller's (ut_calibrate_split).  Every consumer compares the
+ *      largest magnitude its producer stored in THIS call with the calibrated word: an input of 32 x the calibration maximum or
+ *      more is reported as "range check" (see UT_CONV_SPLIT_F16), never silently saturated.
+ *  UT_SPLIT_SCALE_DYNAMIC  the scale word is the one the producing kernel left in this call (the largest magnitude over the
+ *      launch): adapts to any input, but a crop's low-order bits then depend on its batch (at the 1e-7 level). */
+enum { UT_SPLIT_SCALE_CALIBRATED = 0, UT_SPLIT_SCALE_DYNAMIC = 1 };
+int ut_set_split_scale(ut_handle h, int mode);
+/* Replace the calibrated scale words by those of `crops` (device fp32 [n_crops,96,96], the tensor ut_backbone takes;
+ * n_crops == 0: the built-in set).  Synchronous; results of later split-mode calls change at the 1e-7 level with it. */
+int ut_calibrate_split(ut_handle h, const float* crops, int n_crops, void* stream);
+/* The 25 calibrated scale words as floats (host pointer); returns 1 when the handle has not been calibrated yet. */
+int ut_get_split_calibration(ut_handle h, float* out25);
 
 /* Split-fp16 mode only: run each BasicBlock of layer1 (32 -> 32 -> 32 channels at 48x48) as ONE launch whose intermediate
  * relu(bn1(conv1 x)) stays in LDS (csrc/conv_block32.hip) instead of two convolution launches with a round trip through HBM

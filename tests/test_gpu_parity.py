@@ -599,23 +599,96 @@ def test_latency_mode_matches_the_default_to_rounding(engine):
         fast.close()
 
 
-def test_two_backbone_lanes_are_bit_identical(engine):
+@pytest.mark.parametrize("conv", ["fp32", "split_f16"])
+def test_two_backbone_lanes_are_bit_identical(engine, conv):
     """ut_set_backbone_lanes(2): a batch of >= 1024 crops runs as two half-batches on two internal streams (each fills
     the idle tail of the other's launches).  Same kernels on the same crops: same bits, for both crop element types,
-    and the caller's stream sees the joined result (no explicit synchronisation here before the comparison)."""
+    and the caller's stream sees the joined result (no explicit synchronisation here before the comparison).  In split-fp16
+    mode too: the calibrated activation scales do not depend on what a launch holds.  With dynamic scales each half-batch takes
+    its own, and the lanes agree with one lane to the split arithmetic's rounding only."""
+    one = _native.HipEngine(synth.synthetic_state_dict(0), DEV)
     two = _native.HipEngine(synth.synthetic_state_dict(0), DEV)
     try:
+        one.set_conv_arithmetic(conv)
+        two.set_conv_arithmetic(conv)
         two.set_backbone_lanes(2)
         g = torch.Generator(device=DEV)
         g.manual_seed(31)
         for n in (1024, 1501):
             crops = torch.randint(0, 256, (n, 96, 96), device=DEV, generator=g, dtype=torch.uint8).float() / 255.0
-            want = engine.backbone(crops)
+            want = one.backbone(crops)
             got = two.backbone(crops)
             assert torch.equal(got, want), n
-        assert torch.equal(two.backbone(crops[:700]), want[:700])      # below the threshold: one lane
+            if conv == "fp32":
+                assert torch.equal(want, engine.backbone(crops))
+        assert torch.equal(two.backbone(crops[:700]), want[:700])      # below the lane threshold: one lane
+        two.poll_status()
+        if conv != "fp32":
+            one.set_split_scale("dynamic")
+            two.set_split_scale("dynamic")
+            a, b = one.backbone(crops), two.backbone(crops)
+            assert (a - b).abs().max().item() < 2e-6 * max(1.0, a.abs().max().item())
+            assert (a - want).abs().max().item() < 2e-6 * max(1.0, a.abs().max().item())
+            two.poll_status()
     finally:
+        one.close()
         two.close()
+
+
+def test_split_f16_calibrated_scales_batch_independence_and_range_guard(engine):
+    """Calibrated activation scales (the default of the split-fp16 mode; include/umetrack_hip.h::ut_set_split_scale):
+    (i) a crop's features do not depend on its batch - alone, in any sub-batch, at any pass size: the same bits (with dynamic
+    scales they differ in the low bits);  (ii) two handles calibrate to the same words (the built-in set is generated on the
+    device, identically everywhere);  (iii) inputs far beyond the calibrated range are reported, not silently saturated: after a
+    calibration on crops of 1/64 the brightness, crops 64 x brighter still (4096 x the calibration maximum) raise "range check"
+    at the next status read - and run clean with dynamic scales and after a calibration that covers them."""
+    crops = _dev(synth.synthetic_crops(40, seed=17))
+    eng = _native.HipEngine(synth.synthetic_state_dict(0), DEV)
+    other = _native.HipEngine(synth.synthetic_state_dict(0), DEV)
+    try:
+        eng.set_conv_arithmetic("split_f16_always")
+        other.set_conv_arithmetic("split_f16_always")
+        cal = eng.split_calibration()
+        assert np.array_equal(cal, other.split_calibration()) and (cal > 0).all() and np.isfinite(cal).all()
+        whole = eng.backbone(crops)
+        assert torch.equal(eng.backbone(crops[7:8]), whole[7:8])
+        assert torch.equal(eng.backbone(crops[11:29]), whole[11:29])
+        eng.set_backbone_chunk(9)
+        assert torch.equal(eng.backbone(crops), whole)
+        eng.set_backbone_chunk(0)
+        fp32 = engine.backbone(crops)
+        scale = max(1.0, fp32.abs().max().item())
+        assert (whole - fp32).abs().max().item() < 1e-5 * scale
+        eng.poll_status()
+        eng.set_split_scale("dynamic")
+        dyn = eng.backbone(crops)
+        assert (dyn - whole).abs().max().item() < 2e-6 * scale
+        assert not torch.equal(eng.backbone(crops[7:8]), dyn[7:8])          # a launch's own maximum: batch dependent
+        eng.set_split_scale("calibrated")
+        # (iii)
+        eng.calibrate_split(crops / 64.0)
+        assert not np.array_equal(eng.split_calibration(), cal)
+        eng.backbone(crops / 64.0)
+        eng.poll_status()
+        eng.backbone(crops * 64.0)
+        with pytest.raises(FloatingPointError, match="calibrated range"):
+            eng.poll_status()
+        eng.set_split_scale("dynamic")
+        want = engine.backbone(crops * 64.0)
+        got = eng.backbone(crops * 64.0)
+        eng.poll_status()
+        assert (got - want).abs().max().item() < 1e-5 * max(1.0, want.abs().max().item())
+        eng.set_split_scale("calibrated")
+        eng.calibrate_split(crops * 64.0)
+        got = eng.backbone(crops * 64.0)
+        eng.poll_status()
+        assert (got - want).abs().max().item() < 1e-5 * max(1.0, want.abs().max().item())
+        eng.calibrate_split()                                               # back to the built-in set
+        assert np.array_equal(eng.split_calibration(), cal)
+        assert torch.equal(eng.backbone(crops), whole)
+    finally:
+        eng.close()
+        other.close()
 
 
 def _head_inputs(engine, n_samples=3, seed=2):
