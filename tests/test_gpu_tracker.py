@@ -438,3 +438,26 @@ def test_independent_processes_share_the_gpu():
         assert p.returncode == 0, se[-2000:]
         sums.append([ln for ln in so.splitlines() if ln.startswith("SUM")][0])
     assert len(set(sums)) == 1, sums
+
+
+def test_batched_parity_legs_from_raw_images():
+    """oracle/checks.py::batched_parity (the three legs every bench line reports) on 96 label frames, both arithmetics, with the
+    bounds at what the runs measure: identical crop cameras -> identical crops (0 pixels) and every hand-frame inside 1e-4 rad /
+    1e-3 mm; each side's OWN crop cameras with OpenCV's 8-bit remap -> at most 2e-4 of the pixels move by a grey level (the two
+    sides' fp32 forward kinematics of the crop points differ in the last bit, and cv2 rounds coordinates to 1/32 px), the
+    hand-frames whose crops are identical are inside tolerance; own cameras with the float remap (continuous in the coordinates)
+    -> every hand-frame inside tolerance from raw images."""
+    sd = synth.synthetic_state_dict(0)
+    timed = checks.time_oracle(sd, 96, threads=min(16, os.cpu_count() or 1))
+    for out in checks.batched_parity(sd, timed, DEV):
+        n = out["hand_frames"]
+        assert n == timed["hand_frames"] == 192
+        a = out["identical_cameras"]
+        assert a["crop_pixels_differing"] == 0 and a["hand_frames_outside_tolerance"] == 0, out
+        assert a["max_joint_angle_err_rad"] < 1e-4 and a["max_keypoint_err_mm"] < 1e-3
+        b = out["own_cameras_cv2"]
+        assert b["crop_pixel_mismatch_fraction"] <= 2e-4, out
+        assert b["hand_frames_with_identical_crops"] >= 1
+        assert b["hand_frames_outside_tolerance"] <= n - b["hand_frames_with_identical_crops"], out
+        c = out["own_cameras_float"]
+        assert c["hand_frames_outside_tolerance"] == 0 and c["max_crop_abs_diff"] < 1e-4, out
