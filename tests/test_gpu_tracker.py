@@ -1,5 +1,7 @@
 """GPU tests of the host-facing call surface (HandTracker / UmeTrackModel / skin_landmarks through the `lib.*`
 module paths the reference's scripts import) and size-independent properties at BASELINE.json's batch sizes."""
+import os
+
 import numpy as np
 import pytest
 import torch
