@@ -1129,7 +1129,14 @@ static int calibrate_split(ut_handle h, const float* crops, int n, hipStream_t s
   const int arith = h->conv_arith, lanes = h->lanes;
   const bool prof = h->profiling;
   h->conv_arith = UT_CONV_SPLIT_F16_ALWAYS; h->lanes = 1; h->profiling = false; h->calibrating = true;
-  rc = (int)ut::launch_zero_words(h->calib, 32, s) != 0 ? fail(h, UT_E_HIP, "launch_zero_words") : run_backbone(h, crops, nullptr, n, feat, s);
+  const bool fusion = h->block_fusion;
+  rc = (int)ut::launch_zero_words(h->calib, 32, s) != 0 ? fail(h, UT_E_HIP, "launch_zero_words") : UT_OK;
+  // both launch forms of layer1 / layer2's entry: the separate-launch form (ut_set_block_fusion(h, 0)) has two tensors more
+  for (int form = 0; form < 2 && !rc; ++form) {
+    h->block_fusion = form == 0;
+    rc = run_backbone(h, crops, nullptr, n, feat, s);
+  }
+  h->block_fusion = fusion;
   h->conv_arith = arith; h->lanes = lanes; h->profiling = prof; h->calibrating = false;
   if (!rc) {
     HIPCHK(h, ut::launch_raise_words(h->calib, kScaleTensors, kCalibHeadroom, s));
