@@ -457,10 +457,11 @@ class HipEngine:
         """Split-fp16 mode: layer1's BasicBlocks as one launch each (default) or as two convolution launches (A/B tests)."""
         self._check(self.lib.ut_set_block_fusion(self._h, int(bool(on))), "ut_set_block_fusion")
 
-    def set_resident_weights(self, on=True):
-        """Split-fp16 mode: layer2's 64 -> 64 convolutions with the weights resident in registers (conv_c64k.hip, the default)
-        or through the chunked kernel of the other layers (False: A/B tests)."""
-        self._check(self.lib.ut_set_resident_weights(self._h, int(bool(on))), "ut_set_resident_weights")
+    def set_resident_weights(self, kind=1):
+        """Split-fp16 mode, A/B switch: 1 / True (default) layer2's 64 -> 64 convolutions through conv_c64k.hip and layer3 / layer4's
+        stride-1 convolutions through conv_w4.hip; 0 / False everything through the chunked conv_split kernels; 2 conv_c64k only;
+        3 conv_w4 only."""
+        self._check(self.lib.ut_set_resident_weights(self._h, int(kind)), "ut_set_resident_weights")
 
     def set_latency_mode(self, on: bool):
         """Few-crop launches split K across workgroups (per-frame tracking); results then agree with the default mode to

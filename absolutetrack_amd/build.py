@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 OUT = os.path.join(HERE, "libumetrack_hip.so")
-SOURCES = ["ut_api.hip", "conv_igemm.hip", "conv_patch.hip", "conv_block32.hip", "conv_split.hip", "conv_c64k.hip",
+SOURCES = ["ut_api.hip", "conv_igemm.hip", "conv_patch.hip", "conv_block32.hip", "conv_split.hip", "conv_w4.hip", "conv_c64k.hip",
            "conv_c32s2.hip", "stem.hip", "head.hip", "fk.hip", "warp.hip", "cropgen.hip", "homography.hip", "metrics.hip"]
 HEADERS = ["ut_kernels.h", "ut_math.h", "ut_fk.h", os.path.join("..", "..", "include", "umetrack_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

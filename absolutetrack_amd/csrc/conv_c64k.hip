@@ -576,7 +576,7 @@ __global__ __launch_bounds__(512, 1) void conv_c64k_kernel(ConvLaunch p, int n_t
 }
 
 bool conv_c64k_applicable(const ConvLaunch& c) {
-  return !c.no_resident && c.w_split && c.split_unscale > 0.f && c.ksize == 3 && c.stride == 1 && c.pad == 1 && c.cin == 64 && c.cout_store == 64 &&
+  return !(c.no_resident & 1) && c.w_split && c.split_unscale > 0.f && c.ksize == 3 && c.stride == 1 && c.pad == 1 && c.cin == 64 && c.cout_store == 64 &&
          c.cslice == 32 && c.k_pad == 576 && c.cout_pad >= 64 && !c.out_nchw && c.splits == 0 && c.W <= 31 && c.H == c.Ho &&
          c.W == c.Wo && c.H * c.W <= K_MAXHW && c.H * c.W >= K_BM && c.num_cu > 0 &&
          (size_t)c.n_img * c.H * c.W * 64 * sizeof(float) < 0x7FFFFF00ull;

@@ -39,7 +39,8 @@ struct ConvLaunch {
   int device;          // HIP device the launch goes to (the dynamic-LDS attribute is set once per device)
   int num_cu;          // compute units of the device (persistent grid sizing)
   unsigned* tile_counter;   // device word, zero before the launch: dynamic tile queue of the persistent grid
-  int no_resident;     // split kernels: 1 = never the register-resident-weights kernel (ut_set_resident_weights(h, 0): A/B tests)
+  int no_resident;     // split kernels, A/B tests (ut_set_resident_weights): bit 0 = not conv_c64k.hip, bit 1 = not conv_w4.hip
+                       // (the chunked conv_split kernels take those layers)
   int splits;          // > 1 (latency mode): K is cut in `splits` equal chunk ranges, out = [splits][M][cout_store] slabs;
                        // 1 = latency mode without a split (prefers small tiles); 0 = throughput dispatch
 };
@@ -71,6 +72,10 @@ struct Stride2Launch {
 };
 bool conv_c32s2_applicable(const Stride2Launch& c);
 hipError_t launch_conv_c32s2(const Stride2Launch& c, hipStream_t s);
+// 3x3 stride-1 from >= 64 channels to a multiple of 128 channels: four waves of 128 x 64, weights straight from global memory into
+// registers, the patch split on its way into LDS, one barrier per slice (conv_w4.hip); conv_split_kernel<256, 128, 4, 2, true>'s bits
+bool conv_w4_applicable(const ConvLaunch& c);
+hipError_t launch_conv_w4(const ConvLaunch& c, hipStream_t s);
 // 3x3 stride-1 64 -> 64 channels with the weights resident in registers, K split across the two waves of a SIMD (conv_c64k.hip)
 bool conv_c64k_applicable(const ConvLaunch& c);
 hipError_t launch_conv_c64k(const ConvLaunch& c, hipStream_t s);

@@ -161,11 +161,14 @@ int ut_get_split_calibration(ut_handle h, float* out25);
  * an fp32 launch; the shortcut then runs in the split arithmetic too).  0 is for A/B tests. */
 int ut_set_block_fusion(ut_handle h, int on);
 
-/* Split-fp16 mode only: layer2's stride-1 64 -> 64 convolutions with the weights of an output block resident in registers.
- * 1 (default): csrc/conv_c64k.hip - two waves per SIMD share an output block and split its K; their partial sums are added
- *    (slice 0) + (slice 1), so results agree with the chunked kernel's single running sum to fp32 rounding, not bit for bit.
- * 0: the chunked kernel every other layer uses (for A/B tests; its one-wave-per-SIMD predecessor conv_c64r.hip, which has the
- *    chunked kernel's bits, lives under tools/diag/ with its bit-equality check in tools/diag/split_ab.py). */
+/* Split-fp16 mode only: which kernels take the stride-1 3x3 convolutions of layer2 .. layer4 (A/B switch for tests; 1 = default).
+ * csrc/conv_c64k.hip (layer2's 64 -> 64): the weights of an output block resident in registers, two waves per SIMD share the
+ *    block and split its K; partial sums are added (slice 0) + (slice 1), so results agree with the chunked kernel's single
+ *    running sum to fp32 rounding, not bit for bit.
+ * csrc/conv_w4.hip (layer3's 128 -> 128, layer4's 256 -> 256): four waves of 128 x 64, weights global -> registers, the patch split
+ *    on its way into LDS, one barrier per 32-channel slice; the chunked kernel's bits.
+ * 1: both.  0: neither - the chunked kernel (csrc/conv_split.hip) takes every layer.  2: conv_c64k only.  3: conv_w4 only.
+ * (conv_c64k's one-wave-per-SIMD predecessor conv_c64r.hip lives under tools/diag/ with its bit-equality check in split_ab.py.) */
 int ut_set_resident_weights(ut_handle h, int on);
 
 /* Latency mode for calls on a handful of crops (the per-frame tracker): convolutions whose launch has far fewer tiles

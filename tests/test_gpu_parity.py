@@ -128,6 +128,26 @@ def test_split_f16_resident_weight_kernel_against_the_chunked_kernel(engine, spl
     assert (pair - fp32).abs().max().item() < 1e-5 * scale
 
 
+@pytest.mark.parametrize("n_crops", [1, 2, 5, 37, 300])
+def test_split_f16_four_wave_kernel_has_the_chunked_kernel_bits(engine, split_engine, n_crops):
+    """conv_w4.hip (layer3's 128 -> 128 and layer4's 256 -> 256 convolutions: four waves of 128 x 64, weights global -> registers,
+    the patch split on its way into LDS, one barrier per slice) against conv_split_kernel<256, 128, 4, 2, true>: per output element
+    the same products in the same order, so the backbone's features are equal bit for bit.  ut_set_resident_weights(2) routes these
+    layers through the chunked kernel and leaves the rest as it is.  1 crop = 144 / 36 pixels (one ragged 256-row tile per column; at 6x6 fewer
+    rows than one wave's 128), 2 crops = 288 / 72, 5 = 720 / 180, 37 = 5328 / 1332 (ragged last tiles), 300 crops = 169 x 1 and
+    43 x 2 tiles on 256 workgroups (the tile queue hands out second tiles)."""
+    crops = _dev(synth.synthetic_crops(n_crops, seed=51 + n_crops))
+    got = split_engine.backbone(crops)
+    try:
+        split_engine.set_resident_weights(2)             # conv_c64k as in the default, layer3 / layer4 through the chunked kernel
+        chunked = split_engine.backbone(crops)
+    finally:
+        split_engine.set_resident_weights(1)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, chunked)
+    assert torch.equal(split_engine.backbone(crops), got)            # deterministic
+
+
 def test_split_f16_fused_layer1_blocks_match_the_two_launch_form(engine, split_engine):
     """conv_block32.hip (layer1's BasicBlocks as one launch each, the intermediate in LDS) against the same arithmetic as two
     convolution launches per block: the forms differ only in the intermediate's power-of-two scale (a bound there, the

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256, 1) void conv_c64r_kernel(ConvLaunch p, int n_t
   float x_scale = 1.f, x_unscale = 1.f;
   if (p.in_max) {
     bool ok;
-    split_act_scale(p.in_max, x_scale, x_unscale, ok);
+    split_act_scale(p.in_max, nullptr, x_scale, x_unscale, ok);
     if (!ok && tid == 0 && blockIdx.x == 0 && p.status) atomicOr(p.status, UT_SPLIT_RANGE);
   }
   const float tot_unscale = p.split_unscale * x_unscale;

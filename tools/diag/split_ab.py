@@ -74,7 +74,7 @@ variants = [v for v in os.environ.get("SPLIT_VARIANTS", "").split(",") if v]
 ALT_SRC = os.environ.get("SPLIT_ALT_SRC")
 
 
-def build(name, patches, flags=(), alt=None, c64=None, c64k=None):
+def build(name, patches, flags=(), alt=None, c64=None, c64k=None, w4=None):
     src = alt or os.path.join(CSRC, "conv_split.hip")
     if patches:
         text = open(src).read()
@@ -86,7 +86,7 @@ def build(name, patches, flags=(), alt=None, c64=None, c64k=None):
     c64_src = c64 or os.path.join(ROOT, "tools", "diag", "conv_c64r.hip")
     so = f"/tmp/libsplitab_{name}.so"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w", *flags, "-o", so,
-                           os.path.join(CSRC, "conv_igemm.hip"), os.path.join(CSRC, "conv_patch.hip"), c64_src, c64k or os.path.join(CSRC, "conv_c64k.hip"), src,
+                           os.path.join(CSRC, "conv_igemm.hip"), os.path.join(CSRC, "conv_patch.hip"), c64_src, c64k or os.path.join(CSRC, "conv_c64k.hip"), w4 or os.path.join(CSRC, "conv_w4.hip"), src,
                            os.path.join(ROOT, "tools", "diag", "split_entry.hip"), "-I", CSRC])
     return ctypes.CDLL(so)
 
@@ -112,6 +112,9 @@ for nm in [q for q in os.environ.get("C64K_ABL", "").split(",") if q]:      # ti
 for path in [q for q in os.environ.get("C64K_ALT_SRCS", "").split(",") if q]:      # likewise for conv_c64k.hip
     nm = os.path.splitext(os.path.basename(path))[0]
     vlibs["c64k:" + nm] = build("c64k_" + nm, [], c64k=path)
+for path in [q for q in os.environ.get("W4_ALT_SRCS", "").split(",") if q]:      # other versions of conv_w4.hip, timed as w4:<file>
+    nm = os.path.splitext(os.path.basename(path))[0]
+    vlibs["w4:" + nm] = build("w4_" + nm, [], w4=path)
 for path in [q for q in os.environ.get("C64_ALT_SRCS", "").split(",") if q]:
     nm = os.path.splitext(os.path.basename(path))[0]
     vlibs["c64:" + nm] = build("c64_" + nm, [], c64=path)
@@ -176,6 +179,12 @@ flops = 2.0 * n_img * ho * ho * cout * k_total
 cases = [("fp32 mfma", 0, lib), ("split f16x3", 1, lib)] + [(v, 1, l) for v, l in vlibs.items()]
 if cin == 64 and cout == 64 and ksize == 3 and stride == 1:
     cases += [("c64r (one wave/SIMD)", 2, lib), ("chunked 256x64 HALO", 3, lib)]
+if cin >= 64 and cout % 128 == 0 and ksize == 3 and stride == 1:
+    out.fill_(float("nan"))
+    run(3)
+    torch.cuda.synchronize()
+    print(f"conv_w4 == chunked 256x128 HALO bit for bit: {bool(torch.equal(out, b))}")
+    cases += [("chunked 256x128 HALO", 3, lib)]
 times = {name: [] for name, _m, _l in cases}
 import random
 random.seed(1)
