@@ -19,8 +19,8 @@
 //     fp16 pieces and stores the pieces at their padded position - one load, one conversion and two 8-byte LDS stores per k-step,
 //     between the MFMAs; no LDS-DMA, no conversion pass;
 //   * ONE barrier per slice (every 432 MFMAs of a wave): behind it the patch just written is read, the one just read rewritten;
-//   * the epilogue requests a wave's 128 residual values in one go (one memory latency per tile) through two per-lane offset
-//     registers and scalar row offsets.
+//   * the residual of a tile is requested during the tile's last slice (eight loads per k-step, into the free half of the
+//     accumulator file), so the epilogue is scale + bias + residual, ReLU and 128 stores per wave with no load to wait for.
 // Every vector-memory operation is a compiler-visible load or store, so the waits are the compiler's; the order of a k-step's
 // instructions is pinned slot by slot (one MFMA per slot).
 // Same tensors, same weight planes and - per output element - the same products in the same order as
@@ -179,6 +179,8 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
                                   // its registers as soon as this k-step's last MFMA on it has been issued
   u32x4w wf[W4_NSET][NI][2];      // weight fragments (plane 0, plane 1)
   float4 stg[W4_NSTG];            // patch values between their load and their split
+  f32x16w prev[MI][NI];           // the previous tile's accumulators: its epilogue rides under this tile's first slice
+  float rq[3][8];                 // ... its residual values in flight
   const unsigned w_lane = (unsigned)lane * 16u;
 
   // pixel fragment PC (0 first piece, 1 remainder) of block I for k-step half S of tap TAP, base register BASE (buffer included)
@@ -243,30 +245,58 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
     if (i < MI - 1) { W4_READ_X(i, 0, 0, 0, pb) }      // (the last block's first piece: read in slot 0 of its own k-step)
   }
 
+  // The epilogue of a tile runs UNDER the first slice of the workgroup's next tile: the finished accumulators stay where they are
+  // (`prev`), the next tile accumulates in the other half of the accumulator file, and sixteen k-steps of that slice carry eight
+  // residual loads each and, two k-steps later, eight times scale + bias + residual, ReLU, store.  As a phase of its own the
+  // epilogue was a third of a tile's time: with one wave per SIMD nothing overlaps it, and every workgroup of a launch reaches it
+  // at the same moment - 64 MB of residual and output in one burst.  (Weights are loaded W4_DIST = 5 k-steps ahead because the one
+  // vmcnt counter is in order: a wait for a weight fragment also waits for every store issued before its load.)
   // One slice: 18 k-steps of 24 slots, one MFMA per slot.  Slot N of k-step q -
   //   0             the first piece of THIS k-step's last pixel block (its registers were busy until the k-step before ended);
   //   2, 4, 6, 8    the remainder pieces of the next k-step's four pixel blocks;   18, 20, 22  the first pieces of its blocks 0 .. 2
   //                 (k-step 17: of the next slice's / tile's first k-step, out of the other patch buffer);
   //   9 .. 12       the weight fragments of k-step q + W4_DIST;
   //   13            a patch load of the next slice (q < 10);   15   the split and store of the patch load of four k-steps ago;
-#define W4_SLOT_BODY(N)                                                                         \
+  //   EPI slices:   1, 3, 5, 7   two residual loads each of unit q (q < 16);   14, 16, 17, 19 (x2), 21 (x2), 23   one value each of
+  //                 unit q - 2: every load of a k-step is issued before its stores.
+#define W4_EPI_STORE(E)                                                                              \
+          {                                                                                          \
+            const int u_ = q - 2, uj_ = u_ >> 3, ui_ = (u_ >> 1) & 3, r_ = 8 * (u_ & 1) + (E);       \
+            const unsigned o_ = __float_as_uint(fmaxf(fmaf(prev[ui_][uj_][r_], tot_unscale, prev_bb[uj_] + rq[u_ % 3][E]), floor_v)); \
+            unsigned mk_;     /* (an asm max: as a plain max the compiler builds one reduction tree and keeps every value alive for it) */ \
+            asm volatile("v_and_b32 %0, %2, %3\n\tv_max_u32 %1, %1, %0" : "=&v"(mk_), "+v"(out_bits) : "v"(o_), "v"(prev_keep[uj_])); \
+            __builtin_amdgcn_raw_buffer_store_b32(o_, o_rsrc, prev_base[uj_], W4_ROW_OFF(ui_, r_), 0); \
+          }
+#define W4_EPI_LOAD(E)                                                                               \
+          {                                                                                          \
+            const int uj_ = q >> 3, ui_ = (q >> 1) & 3, r_ = 8 * (q & 1) + (E);                      \
+            rq[q % 3][E] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_rsrc, prev_base[uj_], W4_ROW_OFF(ui_, r_), 0)); \
+          }
+#define W4_SLOT_BODY(EPI, N)                                                                         \
         {                                                                                            \
           if ((N) == 0 && q != 17) { W4_READ_X(MI - 1, 0, q & 1, q >> 1, rb) }      /* (k-step 17: in front of the barrier) */ \
-          if ((N) >= 2 && (N) <= 8 && ((N) & 1) == 0 && q1 < 18) { W4_READ_X(((N) / 2 - 1) & 3, 1, q1 & 1, q1 >> 1, rb) } \
-          if ((N) >= 2 && (N) <= 8 && ((N) & 1) == 0 && q1 == 18) { W4_READ_X(((N) / 2 - 1) & 3, 1, 0, 0, wb) } \
-          if ((N) >= 18 && (N) <= 22 && ((N) & 1) == 0 && q1 < 18) { W4_READ_X(((N) / 2 - 9) & 3, 0, q1 & 1, q1 >> 1, rb) } \
-          if ((N) >= 18 && (N) <= 22 && ((N) & 1) == 0 && q1 == 18) { W4_READ_X(((N) / 2 - 9) & 3, 0, 0, 0, wb) } \
-          if ((N) >= 9 && (N) < 13 && qd < 18) { W4_LOAD_W(qd % W4_NSET, ((N) - 9) & 3, ch0 + (qd >> 1), qd & 1, w_row) } \
-          if ((N) >= 9 && (N) < 13 && qd >= 18) { W4_LOAD_W(qd % W4_NSET, ((N) - 9) & 3, ch_after + ((qd - 18) >> 1), qd & 1, row_after) } \
+          if ((N) >= 2 && (N) <= 8 && ((N) & 1) == 0 && q1 < 18) { W4_READ_X((N) / 2 - 1, 1, q1 & 1, q1 >> 1, rb) } \
+          if ((N) >= 2 && (N) <= 8 && ((N) & 1) == 0 && q1 == 18) { W4_READ_X((N) / 2 - 1, 1, 0, 0, wb) } \
+          if ((N) >= 18 && (N) <= 22 && ((N) & 1) == 0 && q1 < 18) { W4_READ_X((N) / 2 - 9, 0, q1 & 1, q1 >> 1, rb) } \
+          if ((N) >= 18 && (N) <= 22 && ((N) & 1) == 0 && q1 == 18) { W4_READ_X((N) / 2 - 9, 0, 0, 0, wb) } \
+          if ((N) >= 9 && (N) < 13 && qd < 18) { W4_LOAD_W(qd % W4_NSET, (N) - 9, ch0 + (qd >> 1), qd & 1, w_row) } \
+          if ((N) >= 9 && (N) < 13 && qd >= 18) { W4_LOAD_W(qd % W4_NSET, (N) - 9, ch_after + ((qd - 18) >> 1), qd & 1, row_after) } \
           if ((N) == 13 && q < W4_NLOAD)                                                             \
             stg[q % W4_NSTG] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, W4_H_OFF(q), f_soff, 0)); \
           if ((N) == 10 && q == 10 && sl == 0 && tid == 0) *reinterpret_cast<int*>(smem + W4_SLOT) = grid + ticket; \
-          if ((N) == 15 && q >= 4 && q < 4 + W4_NLOAD) { W4_STORE_PATCH(stg[(q + W4_NSTG - 4) % W4_NSTG], (q + 6) % 10, wbuf) } \
+          if ((N) == 15 && q >= 4 && q < 4 + W4_NLOAD) { W4_STORE_PATCH(stg[(q - 4) % W4_NSTG], q - 4, wbuf) } \
+          if ((EPI) && q < 16 && ((N) == 1 || (N) == 3 || (N) == 5 || (N) == 7)) { W4_EPI_LOAD((N) - 1) W4_EPI_LOAD(N) } \
+          if ((EPI) && q >= 2 && (N) == 14) { W4_EPI_STORE(0) }                                      \
+          if ((EPI) && q >= 2 && (N) == 16) { W4_EPI_STORE(1) }                                      \
+          if ((EPI) && q >= 2 && (N) == 17) { W4_EPI_STORE(2) }                                      \
+          if ((EPI) && q >= 2 && (N) == 19) { W4_EPI_STORE(3) W4_EPI_STORE(4) }                      \
+          if ((EPI) && q >= 2 && (N) == 21) { W4_EPI_STORE(5) W4_EPI_STORE(6) }                      \
+          if ((EPI) && q >= 2 && (N) == 23) { W4_EPI_STORE(7) }                                      \
           W4_PIN();                                                                                  \
           W4_MFMA(ws, N);                                                                            \
           W4_PIN();                                                                                  \
         }
-#define W4_SLICE()                                                                                   \
+#define W4_SLICE(EPI)                                                                                \
       _Pragma("clang loop unroll(full)") for (int q = 0; q < 18; ++q) {                              \
         const int ws = q % W4_NSET;                                                                  \
         /* (q + 1): the k-step whose pixel fragments are read now; (q + W4_DIST): the k-step whose weights are loaded now */ \
@@ -287,11 +317,16 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
           if (last_slice) W4_P_SETUP(next_tile);    /* the fragments read in this k-step are the next tile's */ \
           _Pragma("unroll") for (int i = 0; i < MI; ++i) wb[i] = pb[i] + wbuf;                       \
         }                                                                                            \
-        W4_SLOT_BODY(0) W4_SLOT_BODY(1) W4_SLOT_BODY(2) W4_SLOT_BODY(3) W4_SLOT_BODY(4) W4_SLOT_BODY(5) \
-        W4_SLOT_BODY(6) W4_SLOT_BODY(7) W4_SLOT_BODY(8) W4_SLOT_BODY(9) W4_SLOT_BODY(10) W4_SLOT_BODY(11) \
-        W4_SLOT_BODY(12) W4_SLOT_BODY(13) W4_SLOT_BODY(14) W4_SLOT_BODY(15) W4_SLOT_BODY(16) W4_SLOT_BODY(17) \
-        W4_SLOT_BODY(18) W4_SLOT_BODY(19) W4_SLOT_BODY(20) W4_SLOT_BODY(21) W4_SLOT_BODY(22) W4_SLOT_BODY(23) \
+        W4_SLOT_BODY(EPI, 0) W4_SLOT_BODY(EPI, 1) W4_SLOT_BODY(EPI, 2) W4_SLOT_BODY(EPI, 3) W4_SLOT_BODY(EPI, 4) W4_SLOT_BODY(EPI, 5) \
+        W4_SLOT_BODY(EPI, 6) W4_SLOT_BODY(EPI, 7) W4_SLOT_BODY(EPI, 8) W4_SLOT_BODY(EPI, 9) W4_SLOT_BODY(EPI, 10) W4_SLOT_BODY(EPI, 11) \
+        W4_SLOT_BODY(EPI, 12) W4_SLOT_BODY(EPI, 13) W4_SLOT_BODY(EPI, 14) W4_SLOT_BODY(EPI, 15) W4_SLOT_BODY(EPI, 16) W4_SLOT_BODY(EPI, 17) \
+        W4_SLOT_BODY(EPI, 18) W4_SLOT_BODY(EPI, 19) W4_SLOT_BODY(EPI, 20) W4_SLOT_BODY(EPI, 21) W4_SLOT_BODY(EPI, 22) W4_SLOT_BODY(EPI, 23) \
       }
+
+  unsigned prev_base[NI] = {0, 0};
+  float prev_bb[NI] = {0.f, 0.f};
+  unsigned prev_keep[NI] = {0, 0};
+  bool has_prev = false;
 
   for (;;) {
     // the tile after this one: the ticket is taken here, written to LDS by thread 0 in the middle of the tile's first slice and
@@ -326,18 +361,23 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
       unsigned rb[MI], wb[MI];
 #pragma unroll
       for (int i = 0; i < MI; ++i) { rb[i] = pb[i] + rbuf; wb[i] = pb[i] + wbuf; }
-      W4_SLICE()
+      if (sl == 0 && has_prev) {
+        W4_SLICE(1)
+      } else {
+        W4_SLICE(0)
+      }
       cur_buf ^= 1;
     }
-    // ---- epilogue: 1 / (weight scale x activation scale) x accumulator + bias + residual, ReLU, store.  The pixels are the
-    // MFMAs' first operand, so a lane's sixteen registers of a block are ONE output channel of sixteen pixels and one dword access
-    // per register covers two whole 128-byte half rows (conv_split.hip); a block's sixteen rows are one per-lane base plus
-    // WAVE-UNIFORM row offsets in the instruction's scalar offset (two offset registers per wave, not one per access).  All 128
-    // residual requests of a wave go out before the first value is needed: one memory latency per tile, not one per block.  The
-    // scalar offset is not part of the descriptor's range check: the tile that reaches beyond the tensor takes per-access offsets.
+    // ---- the tile's accumulators: they become `prev` (their epilogue rides under the next tile's first slice), or - the last tile
+    // of the workgroup, a tile that reaches beyond the tensor - take the stand-alone epilogue: 1 / (weight scale x activation scale)
+    // x accumulator + bias + residual, ReLU, store.  The pixels are the MFMAs' first operand, so a lane's sixteen registers of a
+    // block are ONE output channel of sixteen pixels and one dword access per register covers two whole 128-byte half rows
+    // (conv_split.hip); a block's sixteen rows are one per-lane base plus WAVE-UNIFORM row offsets in the instruction's scalar
+    // offset - which is not part of the descriptor's range check, so the stand-alone form uses per-access offsets.
     {
       const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
       const bool ragged = tm * BM + BM > M;
+      const bool more = (unsigned)next_tile < (unsigned)n_tiles;
       float bb[NI];
       unsigned base[NI];
 #pragma unroll
@@ -346,31 +386,16 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
         bb[j] = p.bias[ch];
         base[j] = ch < p.cout_store ? (unsigned)((tm * BM + wm * (MI * 32) + 4 * fh) * p.cout_store + ch) * 4u : W4_HOOB;
       }
-      if (!ragged) {
-        unsigned row_bs = (unsigned)__builtin_amdgcn_readfirstlane((int)row_b);
-        asm volatile("" : "+s"(row_bs));
-        float rr[NI][MI][16];
+      if (more && !ragged && p.k_pad < 0) {
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int i = 0; i < MI; ++i)
+          for (int j = 0; j < NI; ++j) prev[i][j] = acc[i][j];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-              rr[j][i][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_rsrc, base[j], W4_ROW_OFF(i, r), 0));
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          const unsigned keep_n = base[j] != W4_HOOB ? 0x7FFFFFFFu : 0u;
-#pragma unroll
-          for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const unsigned o = __float_as_uint(fmaxf(fmaf(acc[i][j][r], tot_unscale, bb[j] + rr[j][i][r]), floor_v));
-              unsigned mk;      // (an asm max: as a plain max the compiler builds one reduction tree and keeps every value alive for it)
-              asm volatile("v_and_b32 %0, %2, %3\n\tv_max_u32 %1, %1, %0" : "=&v"(mk), "+v"(out_bits) : "v"(o), "v"(keep_n));
-              __builtin_amdgcn_raw_buffer_store_b32(o, o_rsrc, base[j], W4_ROW_OFF(i, r), 0);
-            }
-        }
+        for (int j = 0; j < NI; ++j) { prev_base[j] = base[j]; prev_bb[j] = bb[j]; prev_keep[j] = base[j] != W4_HOOB ? 0x7FFFFFFFu : 0u; }
+        has_prev = true;
       } else {
+        has_prev = false;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           const unsigned keep_n = base[j] != W4_HOOB ? 0x7FFFFFFFu : 0u;
@@ -412,6 +437,8 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
 #undef W4_ROW_OFF
 #undef W4_STORE_PATCH
 #undef W4_SLOT_BODY
+#undef W4_EPI_LOAD
+#undef W4_EPI_STORE
 #undef W4_SLICE
 }
 

@@ -43,8 +43,8 @@ STAMP_PATCHES = [
 ]
 
 
-def patched(name, patches):
-    text = open(os.path.join(CSRC, "conv_w4.hip")).read()
+def patched(name, patches, src=None):
+    text = open(src or os.path.join(CSRC, "conv_w4.hip")).read()
     for old, new in patches:
         assert old in text, old
         text = text.replace(old, new)
@@ -63,7 +63,8 @@ def build(name, w4=None, flags=()):
 
 
 stamps = bool(os.environ.get("W4_STAMPS"))
-lib = build("stamps", patched("stamps", STAMP_PATCHES), flags=["-DC64_STAMPS"]) if stamps else build("product")
+stamp_src = os.environ.get("W4_STAMPS") if os.path.exists(os.environ.get("W4_STAMPS", "")) else None      # W4_STAMPS=<path>: stamps of that source
+lib = build("stamps", patched("stamps", STAMP_PATCHES, stamp_src), flags=["-DC64_STAMPS"]) if stamps else build("product")
 vlibs = {}
 for nm in [q for q in os.environ.get("W4_ABL", "").split(",") if q]:
     vlibs["abl:" + nm] = build("abl_" + nm.replace("+", "_"), patched(nm.replace("+", "_"), sum((ABL[x] for x in nm.split("+")), [])))
