@@ -75,7 +75,7 @@ template <int WI, int HI>
 __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles_n, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int MI = W4_MI, NI = W4_NI, BM = W4_BM, BN = W4_BN, PW = WI + 1;
-  static_assert(255 + (255 / WI + 2) + (255 / (WI * HI) + 2) * PW + 2 * (PW + 1) < W4_CAP, "the padded tile fits the patch buffer");
+  static_assert(255 + (255 / WI + 2) + (255 / (WI * HI) + 2) * PW + 2 * (PW + 1) < W4_CAP - 1, "the padded tile fits the patch buffer in front of its last row");
   static_assert((W4_LROWS - BM) / 2 >= 2 * WI + 3, "the loaded rows reach every zero row's owner");
 
   const int tid = threadIdx.x;
@@ -115,25 +115,34 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
   // ---- patch stream: thread t loads group t & 7 (four channels) of pixel rows m0 - 32 + 32 j + (t >> 3), j = 0 .. 9, of the tile
   // being fetched.  h_base: the per-lane byte offset of row t >> 3 (rows in front of the tensor wrap far beyond 2^31, rows behind
   // it are behind the descriptor's range: both load zeros with no compare).  h_wa[j]: where the row's first pieces go in the patch
-  // buffer (group (t & 7) >> 1, half t & 1; the remainders four groups on); bit j of h_ok: the row has a place in the buffer; of
+  // buffer (group (t & 7) >> 1, half t & 1; the remainders four groups on); rows without a place go to the buffer's spare last row; bit j of
   // h_xe / h_ye: it ends an image row / sits in an image's last row - it then owns the zero row(s) behind / below it.
   unsigned h_base = 0;
   const unsigned h_step = (unsigned)(32 * p.cin) * 4u;
   unsigned h_wa[W4_NLOAD];
-  unsigned h_ok = 0, h_xe = 0, h_ye = 0, h_xc = 0;      // (h_xc: the row ends an image row, whatever its place)
+  unsigned h_own0 = 0;            // row 0's own place even when it lies in front of the buffer (it may own a zero row inside)
+  unsigned h_xe = 0, h_ye = 0, h_xc = 0;      // (h_xc: the row ends an image row, whatever its place)
 #define W4_H_SETUP(TILE)                                                                             \
   {                                                                                                  \
     const int m0_ = ((TILE) / tiles_n) * BM;                                                         \
     int x0_, y0_;                                                                                    \
     const int lo_ = w4_ppos<WI, HI>(m0_, x0_, y0_) - PW - 1;                                         \
     h_base = (unsigned)((m0_ - 32 + (tid >> 3)) * p.cin + 4 * (tid & 7)) * 4u;                       \
-    h_ok = h_xe = h_ye = h_xc = 0;                                                                   \
+    h_xe = h_ye = h_xc = 0;                                                                            \
+    /* row j is 32 pixels behind row j - 1: its place in the image follows by carries, not by another division */ \
+    int x_, y_;                                                                                      \
+    int rel_ = w4_ppos<WI, HI>(m0_ - 32 + (tid >> 3), x_, y_) - lo_;                                 \
     _Pragma("unroll") for (int j = 0; j < W4_NLOAD; ++j) {                                           \
-      int x_, y_;                                                                                    \
-      const int rel_ = w4_ppos<WI, HI>(m0_ - 32 + 32 * j + (tid >> 3), x_, y_) - lo_;                \
+      if (j > 0) {                                                                                   \
+        x_ += 32 % WI; y_ += 32 / WI; rel_ += (32 / WI) * PW + 32 % WI;                              \
+        if (x_ >= WI) { x_ -= WI; y_ += 1; rel_ += 1; }                                              \
+        if (y_ >= HI) { y_ -= HI; rel_ += PW; }                                                      \
+        if (y_ >= HI) { y_ -= HI; rel_ += PW; }                                                      \
+      }                                                                                              \
       const bool ok_ = rel_ >= 0 && rel_ < W4_CAP;                                                   \
-      h_wa[j] = (unsigned)(rel_ * 16 + ((tid & 7) >> 1) * W4_GSTRIDE + (tid & 1) * 8);               \
-      h_ok |= (ok_ ? 1u : 0u) << j;                                                                  \
+      /* (a row without a place goes to the buffer's last row, which no tile reaches: the stores need no predicate) */ \
+      h_wa[j] = (unsigned)((ok_ ? rel_ : W4_CAP - 1) * 16 + ((tid & 7) >> 1) * W4_GSTRIDE + (tid & 1) * 8); \
+      if (j == 0) h_own0 = (unsigned)(rel_ * 16 + ((tid & 7) >> 1) * W4_GSTRIDE + (tid & 1) * 8);      \
       /* (a zero row inside the buffer is written by its owner even when the owner itself lies in front of the buffer) */ \
       h_xe |= (x_ == WI - 1 && rel_ + 1 >= 0 && rel_ + 1 < W4_CAP ? 1u : 0u) << j;                   \
       h_ye |= (y_ == HI - 1 && rel_ + PW >= 0 && rel_ + PW + 1 < W4_CAP ? 1u : 0u) << j;             \
@@ -146,7 +155,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
 #define W4_H_ZERO(WB)                                                                                \
   {                                                                                                  \
     _Pragma("unroll") for (int j = 0; j < W4_NLOAD; ++j) {                                           \
-      const unsigned a_ = (WB) + h_wa[j];                                                            \
+      const unsigned a_ = (WB) + (j == 0 ? h_own0 : h_wa[j]);                                        \
       const bool xe_ = (h_xe >> j) & 1u, ye_ = (h_ye >> j) & 1u;                                     \
       if (xe_) {                                                                                     \
         *reinterpret_cast<u32x2w*>(smem + a_ + 16u) = u32x2w{0, 0};                                  \
@@ -170,8 +179,16 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
     const int m0_ = ((TILE) / tiles_n) * BM;                                                         \
     int x_, y_;                                                                                      \
     const int p0_ = w4_ppos<WI, HI>(m0_, x_, y_);                                                    \
-    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
-      pb[i] = (unsigned)((w4_ppos<WI, HI>(m0_ + wm * (MI * 32) + i * 32 + fr, x_, y_) - p0_) * 16 + fh * W4_GSTRIDE); \
+    int rel_ = w4_ppos<WI, HI>(m0_ + wm * (MI * 32) + fr, x_, y_) - p0_;                             \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                 \
+      if (i > 0) {                                                                                   \
+        x_ += 32 % WI; y_ += 32 / WI; rel_ += (32 / WI) * PW + 32 % WI;                              \
+        if (x_ >= WI) { x_ -= WI; y_ += 1; rel_ += 1; }                                              \
+        if (y_ >= HI) { y_ -= HI; rel_ += PW; }                                                      \
+        if (y_ >= HI) { y_ -= HI; rel_ += PW; }                                                      \
+      }                                                                                              \
+      pb[i] = (unsigned)(rel_ * 16 + fh * W4_GSTRIDE);                                               \
+    }                                                                                                \
   }
 
   f32x16w acc[MI][NI];
@@ -200,16 +217,14 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
   // (the empty asm keeps memory operations, the scheduling barriers everything else, inside their slot)
 #define W4_PIN() { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
 #define W4_ROW_OFF(I, R) ((unsigned)((I) * 32 + 8 * ((R) >> 2) + ((R) & 3)) * row_bs)
-  // split the patch value loaded as J and store its pieces at their padded place in buffer WB (rows without one: skipped)
+  // split the patch value loaded as J and store its pieces at their padded place in buffer WB (rows without one: the spare last row)
 #define W4_STORE_PATCH(V, J, WB)                                                                     \
   {                                                                                                  \
     unsigned a0_, b0_, a1_, b1_;                                                                     \
     w4_split_pair((V).x, (V).y, x_scale, a0_, b0_);                                                  \
     w4_split_pair((V).z, (V).w, x_scale, a1_, b1_);                                                  \
-    if ((h_ok >> (J)) & 1u) {                                                                        \
-      *reinterpret_cast<u32x2w*>(smem + (WB) + h_wa[J]) = u32x2w{a0_, a1_};                          \
-      *reinterpret_cast<u32x2w*>(smem + (WB) + h_wa[J] + 4 * W4_GSTRIDE) = u32x2w{b0_, b1_};         \
-    }                                                                                                \
+    *reinterpret_cast<u32x2w*>(smem + (WB) + h_wa[J]) = u32x2w{a0_, a1_};                            \
+    *reinterpret_cast<u32x2w*>(smem + (WB) + h_wa[J] + 4 * W4_GSTRIDE) = u32x2w{b0_, b1_};           \
   }
 
   int tile = slot;
@@ -248,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
   //   2, 4, 6, 8    the remainder pieces of the next k-step's four pixel blocks;   18, 20, 22  the first pieces of its blocks 0 .. 2
   //                 (k-step 17: of the next slice's / tile's first k-step, out of the other patch buffer);
   //   9 .. 12       the weight fragments of k-step q + W4_DIST;
-  //   13            a patch load of the next slice (q < 10);   15   the split and store of the patch load of four k-steps ago;
+  //   13            a patch load of the next slice (q < 10);   14, 15   the split and store of the patch load of four k-steps ago;
 #define W4_SLOT_BODY(N)                                                                         \
         {                                                                                            \
           if ((N) == 0 && q != 17) { W4_READ_X(MI - 1, 0, q & 1, q >> 1, rb) }      /* (k-step 17: in front of the barrier) */ \
@@ -261,7 +276,14 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
           if ((N) == 13 && q < W4_NLOAD)                                                             \
             stg[q % W4_NSTG] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, W4_H_OFF(q), f_soff, 0)); \
           if ((N) == 10 && q == 10 && sl == 0 && tid == 0) *reinterpret_cast<int*>(smem + W4_SLOT) = grid + ticket; \
-          if ((N) == 15 && q >= 4 && q < 4 + W4_NLOAD) { W4_STORE_PATCH(stg[(q + W4_NSTG - 4) % W4_NSTG], (q + 6) % 10, wbuf) } \
+          if ((N) == 14 && q >= 4 && q < 4 + W4_NLOAD) { const float4 v_ = stg[(q + W4_NSTG - 4) % W4_NSTG]; w4_split_pair(v_.x, v_.y, x_scale, cv0, cv1); } \
+          if ((N) == 15 && q >= 4 && q < 4 + W4_NLOAD) {                                             \
+            const float4 v_ = stg[(q + W4_NSTG - 4) % W4_NSTG];                                      \
+            unsigned a1_, b1_;                                                                       \
+            w4_split_pair(v_.z, v_.w, x_scale, a1_, b1_);                                            \
+            *reinterpret_cast<u32x2w*>(smem + wbuf + h_wa[(q + 6) % 10]) = u32x2w{cv0, a1_};         \
+            *reinterpret_cast<u32x2w*>(smem + wbuf + h_wa[(q + 6) % 10] + 4 * W4_GSTRIDE) = u32x2w{cv1, b1_}; \
+          }                                                                                          \
           W4_PIN();                                                                                  \
           W4_MFMA(ws, N);                                                                            \
           W4_PIN();                                                                                  \
@@ -269,6 +291,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
 #define W4_SLICE()                                                                                   \
       _Pragma("clang loop unroll(full)") for (int q = 0; q < 18; ++q) {                              \
         const int ws = q % W4_NSET;                                                                  \
+        unsigned cv0 = 0, cv1 = 0;     /* the first half of the patch value being split (slot 14 -> 15) */ \
         /* (q + 1): the k-step whose pixel fragments are read now; (q + W4_DIST): the k-step whose weights are loaded now */ \
         const int q1 = q + 1, qd = q + W4_DIST;                                                      \
         if (q == 17) {                                                                               \
