@@ -130,12 +130,13 @@ def test_split_f16_resident_weight_kernel_against_the_chunked_kernel(engine, spl
 
 @pytest.mark.parametrize("n_crops", [1, 2, 5, 37, 300])
 def test_split_f16_four_wave_kernel_has_the_chunked_kernel_bits(engine, split_engine, n_crops):
-    """conv_w4.hip (layer3's 128 -> 128 and layer4's 256 -> 256 convolutions: four waves of 128 x 64, weights global -> registers,
-    the patch split on its way into LDS, one barrier per slice) against conv_split_kernel<256, 128, 4, 2, true>: per output element
-    the same products in the same order, so the backbone's features are equal bit for bit.  ut_set_resident_weights(2) routes these
-    layers through the chunked kernel and leaves the rest as it is.  1 crop = 144 / 36 pixels (one ragged 256-row tile per column; at 6x6 fewer
-    rows than one wave's 128), 2 crops = 288 / 72, 5 = 720 / 180, 37 = 5328 / 1332 (ragged last tiles), 300 crops = 169 x 1 and
-    43 x 2 tiles on 256 workgroups (the tile queue hands out second tiles)."""
+    """conv_w4.hip (layer3's 128 -> 128 and layer4's 256 -> 256 convolutions: four waves, each all 288 pixels of a tile x 32 output
+    channels; weights global -> registers, the patch split on its way into LDS at padded image coordinates, one barrier per slice)
+    against conv_split_kernel<256, 128, 4, 2, true>: per output element the same products in the same order, so the backbone's
+    features are equal bit for bit.  ut_set_resident_weights(2) routes these layers through the chunked kernel and leaves the rest
+    as it is.  A tile is 2 whole 12x12 maps / 8 whole 6x6 maps: 1 crop = half a tile at 12x12 and an eighth at 6x6 (pixels beyond
+    the tensor inside the only tile), 2 crops = one exact tile at 12x12, 5 and 37 crops = ragged last tiles at both sizes, 300 crops
+    = 150 + 2 x 38 tiles on 256 workgroups (the tile queue hands out second tiles at 6x6)."""
     crops = _dev(synth.synthetic_crops(n_crops, seed=51 + n_crops))
     got = split_engine.backbone(crops)
     try:
