@@ -458,9 +458,9 @@ class HipEngine:
         self._check(self.lib.ut_set_block_fusion(self._h, int(bool(on))), "ut_set_block_fusion")
 
     def set_resident_weights(self, kind=1):
-        """Split-fp16 mode, A/B switch: 1 / True (default) layer2's 64 -> 64 convolutions through conv_c64k.hip and layer3 / layer4's
-        stride-1 convolutions through conv_w4.hip; 0 / False everything through the chunked conv_split kernels; 2 conv_c64k only;
-        3 conv_w4 only."""
+        """Split-fp16 mode, A/B switch (include/umetrack_hip.h::ut_set_resident_weights): 1 / True (default) conv_w4.hip on the
+        stride-1 convolutions of layer2 .. layer4; 0 / False the chunked conv_split kernels everywhere; 2 conv_c64k.hip on layer2,
+        chunked elsewhere; 4 conv_w4 on layer3 / layer4 and conv_c64k on layer2; 5 conv_w4 on layer3 / layer4, chunked on layer2."""
         self._check(self.lib.ut_set_resident_weights(self._h, int(kind)), "ut_set_resident_weights")
 
     def set_latency_mode(self, on: bool):

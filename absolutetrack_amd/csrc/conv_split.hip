@@ -712,10 +712,11 @@ hipError_t launch_conv_split(const ConvLaunch& c, hipStream_t s) {
   if (!conv_split_applicable(c)) return hipErrorInvalidValue;
   if ((size_t)c.n_img * c.H * c.W * c.cin * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
   if ((size_t)c.n_img * c.Ho * c.Wo * c.cout_store * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
-  // layer2's 64 -> 64 convolutions: weights resident in registers (conv_c64k.hip)
-  if (conv_c64k_applicable(c)) return launch_conv_c64k(c, s);
-  // layer3's / layer4's 128 -> 128 and 256 -> 256 convolutions: four waves, no chunk synchronisation (conv_w4.hip; the same bits)
+  // the stride-1 convolutions of layer2 .. layer4 on whole-map tiles: four waves, weights global -> registers, the patch at padded
+  // image coordinates, no chunk synchronisation (conv_w4.hip)
   if (conv_w4_applicable(c)) return launch_conv_w4(c, s);
+  // layer2's 64 -> 64 convolutions with the weights resident in registers (conv_c64k.hip): the form conv_w4 replaced, kept for A/B
+  if (conv_c64k_applicable(c)) return launch_conv_c64k(c, s);
   // stride-1 3x3 from 64 input channels up (image rows of at most 31 pixels): the input halo resident in LDS
   const bool halo = c.ksize == 3 && c.stride == 1 && c.pad == 1 && c.cin >= 64 && c.W <= 31 && c.H == c.Ho && c.W == c.Wo;
   if (c.cout_store <= 64) return halo ? launch_split_cfg<256, 64, 8, 1, true>(c, s) : launch_split_cfg<256, 64, 8, 1, false>(c, s);

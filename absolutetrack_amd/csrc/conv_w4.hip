@@ -41,17 +41,16 @@ typedef unsigned int u32x2w __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8w __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2w __attribute__((ext_vector_type(2)));
 
-constexpr int W4_BM = 288, W4_BN = 128;        // a tile: 288 pixels = 2 whole 12x12 maps / 8 whole 6x6 maps, 128 output channels
-constexpr int W4_MI = 9;                       // 32 x 32 blocks of a wave: all 288 pixels x 32 output channels
-constexpr int W4_NLOAD = W4_BM * 8 / 256;      // float4 patch loads per thread and slice: 9
+constexpr int W4_WPIX = 288;                   // pixels of a wave: nine 32 x 32 blocks against its 32 output channels
+constexpr int W4_MI = 9;
+constexpr int W4_NLOAD = 9;                    // float4 patch loads per thread and slice (288 x 8 = 576 x 4 = 9 x 256)
 constexpr int W4_NSTG = 5;                     // patch loads in flight per thread (loaded in k-step q, split in k-step q + 4)
 constexpr int W4_DIST = 2;                     // weight fragments are loaded this many k-steps ahead
-constexpr int W4_NSET = W4_DIST + 1;           // (18 k-steps % W4_NSET == 0: the register sets line up across slices)
-constexpr int W4_NS = 3 * W4_MI;               // MFMA slots per k-step: 27
+constexpr int W4_NSET = W4_DIST + 1;           // (9 and 18 k-steps % W4_NSET == 0: the register sets line up across slices)
 constexpr unsigned W4_HOOB = 0x80000000u;      // out-of-range offset that stays out of range with a scalar offset added
-static_assert(18 % W4_NSET == 0, "the register sets of the weight fragments line up across slices");
-// per map size: padded rows of a slice patch (the tile's maps, each (H + 1)(W + 1) rows, + W + 2 rows either side), rounded up
-constexpr int w4_cap(int wi, int hi) { return ((W4_BM / (wi * hi)) * (hi + 1) * (wi + 1) + 2 * (wi + 2) + 15) / 16 * 16; }
+static_assert(9 % W4_NSET == 0, "the register sets of the weight fragments line up across slices");
+// padded rows of a slice patch: the tile's maps, each (H + 1)(W + 1) rows, + W + 2 rows either side, rounded up
+constexpr int w4_cap(int pixels, int wi, int hi) { return ((pixels / (wi * hi)) * (hi + 1) * (wi + 1) + 2 * (wi + 2) + 15) / 16 * 16; }
 
 // the pieces of a * s and b * s for a power of two s (conv_split.hip::split_pair_scaled)
 __device__ __forceinline__ void w4_split_pair(float a, float b, float s, unsigned& p0, unsigned& p1) {
@@ -60,25 +59,39 @@ __device__ __forceinline__ void w4_split_pair(float a, float b, float s, unsigne
   p0 = __builtin_bit_cast(unsigned, h);
   p1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
 }
-template <int WI, int HI>
+
+// WI x HI: the map; SCH: input channels per slice (32: two k-steps per tap; 16: one - half the patch bytes, for maps whose padded
+// tile would not fit twice otherwise); WPX: the tile's pixel halves (1: 288 pixels x 128 output channels, the four waves are its four
+// 32-channel blocks; 2: 576 pixels x 64 output channels, waves (pixel half, channel block))
+template <int WI, int HI, int SCH, int WPX>
 __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles_n, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int MI = W4_MI, BM = W4_BM, BN = W4_BN, PW = WI + 1, PH = HI + 1, HW = WI * HI;
-  constexpr int CAP = w4_cap(WI, HI);          // padded rows of a slice patch
-  constexpr int GSTRIDE = CAP * 16;            // bytes between two 16-byte groups of a row: groups 0..3 first pieces, 4..7 remainders
-  constexpr int STAGE = 8 * GSTRIDE;           // one slice patch (12x12: 46 KB, 6x6: 52 KB)
-  constexpr int SLOT = 2 * STAGE;              // the next tile's index
+  constexpr int MI = W4_MI, PW = WI + 1, PH = HI + 1, HW = WI * HI;
+  constexpr int BM = W4_WPIX * WPX;            // pixels of a tile: whole maps
+  constexpr int NCB = 4 / WPX, BN = 32 * NCB;  // 32-channel blocks / output channels of a tile
+  constexpr int NG = SCH / 4, NHG = NG / 2;    // 16-byte groups of a patch row: NHG of first pieces, then NHG of remainders
+  constexpr int KS = 9 * SCH / 16;             // k-steps of a slice
+  constexpr int NBUF = SCH == 32 ? 2 : 3;      // patch buffers; the patch of slice h + NBUF - 1 is fetched during slice h
+  constexpr int AHEAD = NBUF - 1;
+  constexpr int RP = 256 / NG;                 // pixel rows per pass of the patch stream
+  constexpr int CAP = w4_cap(BM, WI, HI);      // padded rows of a slice patch
+  constexpr int GSTRIDE = CAP * 16;            // bytes between two 16-byte groups of a row
+  constexpr int STAGE = NG * GSTRIDE;          // one slice patch (12x12: 46 KB, 6x6: 52 KB, 24x24 in 16-channel slices: 43 KB)
+  constexpr int SLOT = NBUF * STAGE;           // the next tile's index
   static_assert(BM % HW == 0, "a tile is a whole number of maps: every tile has the same padded layout");
-  static_assert(6 * GSTRIDE + (2 * PW + 2) * 16 < 65536, "fragment reads: everything but the lane's base fits the immediate offset");
+  static_assert(BM * NG == W4_NLOAD * 256 && KS % W4_NSET == 0 && (SCH == 32 || SCH == 16) && (WPX == 1 || WPX == 2), "shape");
+  static_assert((NG - 2) * GSTRIDE + (2 * PW + 2) * 16 < 65536, "fragment reads: everything but the lane's base fits the immediate offset");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = the wave's 32-channel block of the tile's 128 output channels
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = WPX == 1 ? 0 : wave >> 1;     // the wave's pixel half
+  const int wco = WPX == 1 ? wave : wave & 1;  // ... and 32-channel block of the tile
   const int fr = lane & 31, fh = lane >> 5;
 
   const int M = p.n_img * HW;
-  const int n_slices = p.cin / 32;
-  const int n_chunks = p.k_pad / 32;           // 9 * n_slices
+  const int n_slices = p.cin / SCH;
+  const int n_chunks = p.k_pad / 32;           // 9 per 32 input channels
 
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.in), 0, (int)((size_t)M * p.cin * sizeof(float)), 0x00020000);
@@ -106,24 +119,25 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
 
   // ---- the padded layout, the same for every tile (a tile starts on a map): pixel k of the tile - map k / HW, row y, column x -
   // sits at padded row PW + 1 + (k / HW) PH PW + y PW + x; the rows in between are zeroed once, in the prologue, and never written.
-  // Patch stream: thread t loads group t & 7 (four channels) of the tile's pixels 32 j + (t >> 3), j = 0 .. 8; h_wa[j]: where
-  // their first pieces go (group (t & 7) >> 1, half t & 1; the remainders four groups on).
-  // Read side: pb[i]: the lane's pixel 32 i + fr, + its k half as a group; taps, k-step halves and pieces are immediates.
+  // Patch stream: thread t loads group t % NG (four channels) of the tile's pixels RP j + t / NG, j = 0 .. 8; h_wa[j]: where their
+  // first pieces go (group (t % NG) >> 1, half t & 1; the remainders NHG groups on).
+  // Read side: pb[i]: the lane's pixel (of the wave's 288) 32 i + fr, + its k half as a group; taps, k-step halves and pieces are
+  // immediates.
   unsigned h_wa[W4_NLOAD], pb[MI];
 #pragma unroll
   for (int j = 0; j < W4_NLOAD; ++j) {
-    const int k = 32 * j + (tid >> 3), img = k / HW, rem = k - img * HW, y = rem / WI, x = rem - y * WI;
-    h_wa[j] = (unsigned)((PW + 1 + img * (PH * PW) + y * PW + x) * 16 + ((tid & 7) >> 1) * GSTRIDE + (tid & 1) * 8);
+    const int k = RP * j + tid / NG, img = k / HW, rem = k - img * HW, y = rem / WI, x = rem - y * WI;
+    h_wa[j] = (unsigned)((PW + 1 + img * (PH * PW) + y * PW + x) * 16 + ((tid % NG) >> 1) * GSTRIDE + (tid & 1) * 8);
   }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const int k = 32 * i + fr, img = k / HW, rem = k - img * HW, y = rem / WI, x = rem - y * WI;
+    const int k = wm * W4_WPIX + 32 * i + fr, img = k / HW, rem = k - img * HW, y = rem / WI, x = rem - y * WI;
     pb[i] = (unsigned)((img * (PH * PW) + y * PW + x) * 16 + fh * GSTRIDE);
   }
-  const unsigned h_step = (unsigned)(32 * p.cin) * 4u;
-  // per-lane byte offset of pixel t >> 3 of the tile being fetched (pixels behind the tensor are behind the descriptor's range:
-  // they load zeros); +j h_step per load
-#define W4_H_BASE(TILE) ((unsigned)((((TILE) / tiles_n) * BM + (tid >> 3)) * p.cin + 4 * (tid & 7)) * 4u)
+  const unsigned h_step = (unsigned)(RP * p.cin) * 4u;
+  // per-lane byte offset of pixel t / NG of a tile (pixels behind the tensor are behind the descriptor's range: they load zeros);
+  // + j h_step per load, + the slice's channel offset as the scalar offset
+#define W4_H_BASE(TILE) ((unsigned)((((TILE) / tiles_n) * BM + tid / NG) * p.cin + 4 * (tid % NG)) * 4u)
 
   f32x16w acc[MI];
   u32x4w xp[MI][2];               // pixel fragments (first piece, remainder): ONE set - a fragment of the next k-step is read into its
@@ -132,15 +146,20 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
   float4 stg[W4_NSTG];            // patch values between their load and their split
   const unsigned w_lane = (unsigned)lane * 16u;
 
-  // pixel fragment PC (0 first piece, 1 remainder) of block I for k-step half S of tap TAP, base register BASE (buffer included)
+  // pixel fragment PC (0 first piece, 1 remainder) of block I for k-step half S (SCH == 32) of tap TAP, base register BASE (buffer
+  // included)
 #define W4_READ_X(I, PC, S, TAP, BASE)                                                               \
-  xp[I][PC] = *reinterpret_cast<const u32x4w*>(smem + (BASE)[I] + (unsigned)(((PC) * 4 + 2 * (S)) * GSTRIDE + (((TAP) / 3) * PW + (TAP) % 3) * 16));
+  xp[I][PC] = *reinterpret_cast<const u32x4w*>(smem + (BASE)[I] + (unsigned)(((PC) * NHG + (SCH == 32 ? 2 * (S) : 0)) * GSTRIDE + (((TAP) / 3) * PW + (TAP) % 3) * 16));
   // weight fragment of plane PL of chunk CH, k-step half S, of the wave's block of the tile column at byte offset WROW
 #define W4_LOAD_W(SET, PL, CH, S, WROW)                                                              \
   {                                                                                                  \
-    const unsigned so_ = (WROW) + (unsigned)((wave * n_chunks + (CH)) * 4096 + ((S) * 2 + (PL)) * 1024); \
+    const unsigned so_ = (WROW) + (unsigned)((wco * n_chunks + (CH)) * 4096 + ((S) * 2 + (PL)) * 1024); \
     wf[SET][PL] = __builtin_bit_cast(u32x4w, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane, so_, 0)); \
   }
+  // k-step Q of slice SL: its tap, its chunk of the weight planes and its half of the chunk
+#define W4_TAP(Q) (SCH == 32 ? (Q) >> 1 : (Q))
+#define W4_CHUNK(SL, Q) (SCH == 32 ? (SL) * 9 + ((Q) >> 1) : ((SL) >> 1) * 9 + (Q))
+#define W4_HALF(SL, Q) (SCH == 32 ? (Q) & 1 : (SL) & 1)
 #define W4_MFMA(WSET, N)                                                                             \
   {                                                                                                  \
     constexpr int pr_ = (N) / MI, i_ = (N) % MI;                                                     \
@@ -151,31 +170,40 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
   // (the empty asm keeps memory operations, the scheduling barriers everything else, inside their slot)
 #define W4_PIN() { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
 #define W4_ROW_OFF(I, R) ((unsigned)((I) * 32 + 8 * ((R) >> 2) + ((R) & 3)) * row_bs)
+#define W4_SPLIT_STORE(V, WA)                                                                        \
+  {                                                                                                  \
+    unsigned a0_, b0_, a1_, b1_;                                                                     \
+    w4_split_pair((V).x, (V).y, x_scale, a0_, b0_);                                                  \
+    w4_split_pair((V).z, (V).w, x_scale, a1_, b1_);                                                  \
+    *reinterpret_cast<u32x2w*>(smem + (WA)) = u32x2w{a0_, a1_};                                      \
+    *reinterpret_cast<u32x2w*>(smem + (WA) + NHG * GSTRIDE) = u32x2w{b0_, b1_};                      \
+  }
 
   int tile = slot;
   int next_tile = 0;
-  int cur_buf = 0;                // patch buffer (0 / 1) of the slice being computed
+  int cur_buf = 0;                // patch buffer of the slice being computed
   unsigned out_bits = 0;
   const unsigned slot_addr = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem + (unsigned)SLOT;
 
-  // ---- prologue (exposed once per workgroup): both patch buffers zeroed (their zero rows stay zero for the life of the workgroup),
-  // the first tile's first patch, the weights of its first W4_DIST k-steps and the pixel fragments of its first
-  for (int k = tid; k < 2 * STAGE / 16; k += 256) *reinterpret_cast<u32x4w*>(smem + k * 16) = u32x4w{0, 0, 0, 0};
+  // ---- prologue (exposed once per workgroup): the patch buffers zeroed (their zero rows stay zero for the life of the workgroup),
+  // the patches of the first tile's first AHEAD slices (of the last of them, with three buffers: only what the steady state would
+  // have stored by now - the rest stays in its registers for the first slice's first k-steps), the weights of the first W4_DIST
+  // k-steps and the pixel fragments of the first
+  for (int k = tid; k < NBUF * STAGE / 16; k += 256) *reinterpret_cast<u32x4w*>(smem + k * 16) = u32x4w{0, 0, 0, 0};
   __syncthreads();
   unsigned h_base = W4_H_BASE(tile);
 #pragma unroll
-  for (int j = 0; j < W4_NLOAD; ++j) {
-    const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, h_base + (unsigned)j * h_step, 0, 0));
-    unsigned a0, b0, a1, b1;
-    w4_split_pair(v.x, v.y, x_scale, a0, b0);
-    w4_split_pair(v.z, v.w, x_scale, a1, b1);
-    *reinterpret_cast<u32x2w*>(smem + h_wa[j]) = u32x2w{a0, a1};
-    *reinterpret_cast<u32x2w*>(smem + h_wa[j] + 4 * GSTRIDE) = u32x2w{b0, b1};
-  }
-  unsigned w_row = (unsigned)((tile % tiles_n) * (BN / 32)) * (unsigned)n_chunks * 4096u;     // byte offset of the tile column's planes
+  for (int a = 0; a < AHEAD; ++a)
+#pragma unroll
+    for (int j = 0; j < W4_NLOAD; ++j) {
+      const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, h_base + (unsigned)j * h_step, (unsigned)(a * SCH * 4), 0));
+      if (a == AHEAD - 1 && KS == 9 && j >= W4_NLOAD - 4) stg[j % W4_NSTG] = v;
+      else W4_SPLIT_STORE(v, (unsigned)(a * STAGE) + h_wa[j])
+    }
+  unsigned w_row = (unsigned)((tile % tiles_n) * NCB) * (unsigned)n_chunks * 4096u;     // byte offset of the tile column's planes
   unsigned w_row_next = w_row;
 #pragma unroll
-  for (int g = 0; g < W4_DIST; ++g) { W4_LOAD_W(g, 0, g >> 1, g & 1, w_row) W4_LOAD_W(g, 1, g >> 1, g & 1, w_row) }
+  for (int g = 0; g < W4_DIST; ++g) { W4_LOAD_W(g, 0, W4_CHUNK(0, g), W4_HALF(0, g), w_row) W4_LOAD_W(g, 1, W4_CHUNK(0, g), W4_HALF(0, g), w_row) }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
@@ -183,47 +211,56 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
     if (i < MI - 1) { W4_READ_X(i, 0, 0, 0, pb) }      // (the last block's first piece: read in slot 0 of its own k-step)
   }
 
-  // One slice: 18 k-steps of 27 slots, one MFMA per slot (products x1 w0 of the nine pixel blocks, then x0 w1, then x0 w0).  Slot N of
+  // One slice: KS k-steps of 27 slots, one MFMA per slot (products x1 w0 of the nine pixel blocks, then x0 w1, then x0 w0).  Slot N of
   // k-step q -
   //   0             the first piece of THIS k-step's last pixel block (its registers were busy until the k-step before ended);
   //   1 .. 9        the remainder pieces of the next k-step's nine pixel blocks;   19 .. 26   the first pieces of its blocks 0 .. 7
-  //                 (k-step 17: of the next slice's / tile's first k-step, out of the other patch buffer);
+  //                 (last k-step: of the next slice's / tile's first k-step, out of the next patch buffer);
   //   10, 11        the two weight fragments of k-step q + W4_DIST;
-  //   12            a patch load of the next slice (q < 9);   13, 14   the split and store of the patch load of four k-steps ago.
+  //   12, 13        the split and store of the patch value loaded four k-steps ago (with 9-step slices the first four k-steps finish
+  //                 the patch the slice before began);   14   a patch load of slice + AHEAD (q < 9).
 #define W4_SLOT_BODY(N)                                                                              \
         {                                                                                            \
-          if ((N) == 0 && q != 17) { W4_READ_X(MI - 1, 0, q & 1, q >> 1, rb) }      /* (k-step 17: in front of the barrier) */ \
-          if ((N) >= 1 && (N) <= 9 && q1 < 18) { W4_READ_X(((N) + 8) % 9, 1, q1 & 1, q1 >> 1, rb) }  \
-          if ((N) >= 1 && (N) <= 9 && q1 == 18) { W4_READ_X(((N) + 8) % 9, 1, 0, 0, wb) }            \
-          if ((N) >= 19 && (N) <= 26 && q1 < 18) { W4_READ_X(((N) + 8) % 9, 0, q1 & 1, q1 >> 1, rb) } \
-          if ((N) >= 19 && (N) <= 26 && q1 == 18) { W4_READ_X(((N) + 8) % 9, 0, 0, 0, wb) }          \
-          if (((N) == 10 || (N) == 11) && qd < 18) { W4_LOAD_W(qd % W4_NSET, (N) & 1, ch0 + (qd >> 1), qd & 1, w_row) } \
-          if (((N) == 10 || (N) == 11) && qd >= 18) { W4_LOAD_W(qd % W4_NSET, (N) & 1, ch_after + ((qd - 18) >> 1), qd & 1, row_after) } \
-          if ((N) == 12 && q < W4_NLOAD)                                                             \
-            stg[q % W4_NSTG] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, h_base + (unsigned)q * h_step, f_soff, 0)); \
-          if ((N) == 15 && q == 10 && sl == 0 && tid == 0) *reinterpret_cast<int*>(smem + SLOT) = grid + ticket; \
-          if ((N) == 13 && q >= 4 && q < 4 + W4_NLOAD) { const float4 v_ = stg[(q + W4_NSTG - 4) % W4_NSTG]; w4_split_pair(v_.x, v_.y, x_scale, cv0, cv1); } \
-          if ((N) == 14 && q >= 4 && q < 4 + W4_NLOAD) {                                             \
+          if ((N) == 0 && q != KS - 1) { W4_READ_X(MI - 1, 0, W4_HALF(sl, q), W4_TAP(q), rb) }      /* (last k-step: in front of the barrier) */ \
+          if ((N) >= 1 && (N) <= 9 && q1 < KS) { W4_READ_X(((N) + 8) % 9, 1, W4_HALF(sl, q1), W4_TAP(q1), rb) } \
+          if ((N) >= 1 && (N) <= 9 && q1 == KS) { W4_READ_X(((N) + 8) % 9, 1, 0, 0, nb) }            \
+          if ((N) >= 19 && (N) <= 26 && q1 < KS) { W4_READ_X(((N) + 8) % 9, 0, W4_HALF(sl, q1), W4_TAP(q1), rb) } \
+          if ((N) >= 19 && (N) <= 26 && q1 == KS) { W4_READ_X(((N) + 8) % 9, 0, 0, 0, nb) }          \
+          if (((N) == 10 || (N) == 11) && qd < KS) { W4_LOAD_W(qd % W4_NSET, (N) & 1, W4_CHUNK(sl, qd), W4_HALF(sl, qd), w_row) } \
+          if (((N) == 10 || (N) == 11) && qd >= KS) { W4_LOAD_W(qd % W4_NSET, (N) & 1, W4_CHUNK(sl_after, qd - KS), W4_HALF(sl_after, qd - KS), row_after) } \
+          if ((N) == 12 && q >= 4 && q < 4 + W4_NLOAD) { const float4 v_ = stg[(q + W4_NSTG - 4) % W4_NSTG]; w4_split_pair(v_.x, v_.y, x_scale, cv0, cv1); } \
+          if ((N) == 13 && q >= 4 && q < 4 + W4_NLOAD) {                                             \
             const float4 v_ = stg[(q + W4_NSTG - 4) % W4_NSTG];                                      \
             unsigned a1_, b1_;                                                                       \
             w4_split_pair(v_.z, v_.w, x_scale, a1_, b1_);                                            \
             *reinterpret_cast<u32x2w*>(smem + wbuf + h_wa[(q + 5) % 9]) = u32x2w{cv0, a1_};          \
-            *reinterpret_cast<u32x2w*>(smem + wbuf + h_wa[(q + 5) % 9] + 4 * GSTRIDE) = u32x2w{cv1, b1_}; \
+            *reinterpret_cast<u32x2w*>(smem + wbuf + h_wa[(q + 5) % 9] + NHG * GSTRIDE) = u32x2w{cv1, b1_}; \
           }                                                                                          \
+          if (KS == 9 && (N) == 12 && q < 4) { const float4 v_ = stg[q % W4_NSTG]; w4_split_pair(v_.x, v_.y, x_scale, cv0, cv1); } \
+          if (KS == 9 && (N) == 13 && q < 4) {      /* values 5 .. 8 of the patch the slice before began: the buffer before wbuf */ \
+            const float4 v_ = stg[q % W4_NSTG];                                                      \
+            unsigned a1_, b1_;                                                                       \
+            w4_split_pair(v_.z, v_.w, x_scale, a1_, b1_);                                            \
+            *reinterpret_cast<u32x2w*>(smem + pbuf + h_wa[q + 5]) = u32x2w{cv0, a1_};                \
+            *reinterpret_cast<u32x2w*>(smem + pbuf + h_wa[q + 5] + NHG * GSTRIDE) = u32x2w{cv1, b1_}; \
+          }                                                                                          \
+          if ((N) == 14 && q < W4_NLOAD)                                                             \
+            stg[q % W4_NSTG] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, h_base + (unsigned)q * h_step, f_soff, 0)); \
+          if ((N) == 16 && q == KS / 2 && sl == 0 && tid == 0) *reinterpret_cast<int*>(smem + SLOT) = grid + ticket; \
           W4_PIN();                                                                                  \
           W4_MFMA(ws, N);                                                                            \
           W4_PIN();                                                                                  \
         }
 #define W4_SLICE()                                                                                   \
-      _Pragma("clang loop unroll(full)") for (int q = 0; q < 18; ++q) {                              \
+      _Pragma("clang loop unroll(full)") for (int q = 0; q < KS; ++q) {                              \
         const int ws = q % W4_NSET;                                                                  \
-        unsigned cv0 = 0, cv1 = 0;     /* the first half of the patch value being split (slot 13 -> 14) */ \
+        unsigned cv0 = 0, cv1 = 0;     /* the first half of the patch value being split (slot 12 -> 13) */ \
         /* (q + 1): the k-step whose pixel fragments are read now; (q + W4_DIST): the k-step whose weights are loaded now */ \
         const int q1 = q + 1, qd = q + W4_DIST;                                                      \
-        if (q == 17) {                                                                               \
-          /* every wave has written its part of the next patch (k-steps 4 .. 12) and has read its last fragments of this one: \
-             ONE barrier per slice, in front of the first reads of the next patch */                 \
-          W4_READ_X(MI - 1, 0, 1, 8, rb)                                                             \
+        if (q == KS - 1) {                                                                           \
+          /* every wave has written its part of the next slice's patch and has read its last fragments of this one: ONE barrier \
+             per slice, in front of the first reads of the next patch */                             \
+          W4_READ_X(MI - 1, 0, W4_HALF(sl, KS - 1), 8, rb)                                           \
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
           __builtin_amdgcn_s_barrier();                                                              \
           asm volatile("" ::: "memory");                                                             \
@@ -231,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
             int nv;                                                                                  \
             asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nv) : "v"(slot_addr) : "memory"); \
             next_tile = __builtin_amdgcn_readfirstlane(nv);                                          \
-            w_row_next = (unsigned)((next_tile % tiles_n) * (BN / 32)) * (unsigned)n_chunks * 4096u; \
+            w_row_next = (unsigned)((next_tile % tiles_n) * NCB) * (unsigned)n_chunks * 4096u;       \
           }                                                                                          \
         }                                                                                            \
         W4_SLOT_BODY(0) W4_SLOT_BODY(1) W4_SLOT_BODY(2) W4_SLOT_BODY(3) W4_SLOT_BODY(4) W4_SLOT_BODY(5) W4_SLOT_BODY(6) W4_SLOT_BODY(7) W4_SLOT_BODY(8) \
@@ -241,7 +278,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
 
   for (;;) {
     // the tile after this one: the ticket is taken here, written to LDS by thread 0 in the middle of the tile's first slice and
-    // read by everyone behind that slice's barrier (a tile has at least two slices)
+    // read by everyone behind that slice's barrier (a tile has at least AHEAD + 1 slices)
     int ticket = 0;
     if (tid == 0) ticket = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, q_rsrc, 0, 0, 0);
 #pragma unroll
@@ -251,20 +288,24 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
 
     for (int sl = 0; sl < n_slices; ++sl) {
       const bool last_slice = sl == n_slices - 1;
-      unsigned rbuf = (unsigned)__builtin_amdgcn_readfirstlane(cur_buf * STAGE), wbuf = (unsigned)__builtin_amdgcn_readfirstlane((cur_buf ^ 1) * STAGE);
-      asm volatile("" : "+s"(rbuf), "+s"(wbuf));      // (opaque per slice: nothing derived from them is carried across slices)
-      // the patch fetched during this slice: the next slice of this tile, or slice 0 of the next tile
-      if (last_slice) h_base = W4_H_BASE(next_tile);
-      const unsigned f_soff = last_slice ? 0u : (unsigned)(sl + 1) * 128u;
-      const int ch0 = sl * 9;
-      // the weight fragments of the k-steps behind this slice: the next slice's first chunks, or the next tile's
-      const int ch_after = last_slice ? 0 : ch0 + 9;
+      // the buffers: read this slice's patch, the next slice's (its first fragments are read in this slice's last k-step), the
+      // patch being begun (slice + AHEAD) and - three buffers - the one the slice before began and this slice finishes
+      const int b1 = cur_buf + 1 == NBUF ? 0 : cur_buf + 1, b2 = b1 + 1 == NBUF ? 0 : b1 + 1;
+      unsigned rbuf = (unsigned)__builtin_amdgcn_readfirstlane(cur_buf * STAGE), nbuf = (unsigned)__builtin_amdgcn_readfirstlane(b1 * STAGE);
+      unsigned wbuf = (unsigned)__builtin_amdgcn_readfirstlane((NBUF == 2 ? b1 : b2) * STAGE), pbuf = nbuf;
+      asm volatile("" : "+s"(rbuf), "+s"(nbuf), "+s"(wbuf), "+s"(pbuf));      // (opaque per slice: nothing derived from them is carried across slices)
+      // the patch begun during this slice: slice + AHEAD of this tile, or of the next
+      const int f_sl = sl + AHEAD < n_slices ? sl + AHEAD : sl + AHEAD - n_slices;
+      if (sl + AHEAD == n_slices) h_base = W4_H_BASE(next_tile);
+      const unsigned f_soff = (unsigned)f_sl * (SCH * 4);
+      // the weight fragments of the k-steps behind this slice: the next slice's, or the next tile's first
+      const int sl_after = last_slice ? 0 : sl + 1;
       const unsigned row_after = last_slice ? w_row_next : w_row;
-      unsigned rb[MI], wb[MI];
+      unsigned rb[MI], nb[MI];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) { rb[i] = pb[i] + rbuf; wb[i] = pb[i] + wbuf; }
+      for (int i = 0; i < MI; ++i) { rb[i] = pb[i] + rbuf; nb[i] = pb[i] + nbuf; }
       W4_SLICE()
-      cur_buf ^= 1;
+      cur_buf = b1;
     }
     // ---- epilogue: 1 / (weight scale x activation scale) x accumulator + bias + residual, ReLU, store.  The pixels are the
     // MFMAs' first operand, so a lane's sixteen registers of a block are ONE output channel of sixteen pixels and one dword access
@@ -275,9 +316,9 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
     {
       const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
       const bool ragged = tm * BM + BM > M;
-      const int ch = tn * BN + wave * 32 + fr;
+      const int ch = tn * BN + wco * 32 + fr;
       const float bb = p.bias[ch];
-      const unsigned base = ch < p.cout_store ? (unsigned)((tm * BM + 4 * fh) * p.cout_store + ch) * 4u : W4_HOOB;
+      const unsigned base = ch < p.cout_store ? (unsigned)((tm * BM + wm * W4_WPIX + 4 * fh) * p.cout_store + ch) * 4u : W4_HOOB;
       const unsigned keep_n = base != W4_HOOB ? 0x7FFFFFFFu : 0u;
       if (!ragged) {
         unsigned row_bs = (unsigned)__builtin_amdgcn_readfirstlane((int)row_b);
@@ -318,7 +359,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const unsigned o = __float_as_uint(fmaxf(fmaf(acc[i][r], tot_unscale, bb + r1[r]), floor_v));
-            const int pix = i * 32 + 8 * (r >> 2) + 4 * fh + (r & 3);
+            const int pix = wm * W4_WPIX + i * 32 + 8 * (r >> 2) + 4 * fh + (r & 3);
             out_bits = max(out_bits, o & (tm * BM + pix < M ? keep_n : 0u));
             __builtin_amdgcn_raw_buffer_store_b32(o, o_rsrc, off, 0, 0);
             off += ((r & 3) == 3 ? 5u : 1u) * row_b;
@@ -334,46 +375,56 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
 #undef W4_H_BASE
 #undef W4_READ_X
 #undef W4_LOAD_W
+#undef W4_TAP
+#undef W4_CHUNK
+#undef W4_HALF
 #undef W4_MFMA
 #undef W4_PIN
 #undef W4_ROW_OFF
+#undef W4_SPLIT_STORE
 #undef W4_SLOT_BODY
 #undef W4_SLICE
 }
 
-template <int WI, int HI>
+template <int WI, int HI, int SCH, int WPX>
 hipError_t launch_w4_cfg(const ConvLaunch& c, hipStream_t s) {
+  constexpr int BM = W4_WPIX * WPX, BN = 128 / WPX;
   const long M = (long)c.n_img * c.H * c.W;
-  const int tiles_m = (int)((M + W4_BM - 1) / W4_BM), tiles_n = c.cout_store / W4_BN;
+  const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = c.cout_store / BN;
   const int n_tiles = tiles_m * tiles_n;
-  constexpr int lds = 2 * 8 * w4_cap(WI, HI) * 16 + 16;
+  constexpr int lds = (SCH == 32 ? 2 : 3) * (SCH / 4) * w4_cap(BM, WI, HI) * 16 + 16;
   static std::atomic<unsigned long long> attr_set{0};
   const unsigned long long dev_bit = (c.device >= 0 && c.device < 64) ? 1ull << c.device : 0ull;
   if (!(attr_set.load(std::memory_order_relaxed) & dev_bit) || !dev_bit) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_w4_kernel<WI, HI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_w4_kernel<WI, HI, SCH, WPX>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_set.fetch_or(dev_bit, std::memory_order_relaxed);
   }
   int grid = c.num_cu;
   if (grid > n_tiles) grid = n_tiles;
-  hipLaunchKernelGGL((conv_w4_kernel<WI, HI>), dim3(grid), dim3(256), lds, s, c, tiles_n, n_tiles);
+  hipLaunchKernelGGL((conv_w4_kernel<WI, HI, SCH, WPX>), dim3(grid), dim3(256), lds, s, c, tiles_n, n_tiles);
   return hipGetLastError();
 }
 
 }  // namespace
 
-// (the map sizes are template parameters - taps and padded rows are immediates of the fragment reads: the backbone's 12x12 and 6x6)
+// (the map sizes are template parameters - taps and padded rows are immediates of the fragment reads: the backbone's 12x12 and 6x6 maps
+// with 128-channel tiles, its 24x24 maps with 64 -> 64 channels as tiles of one whole map)
 bool conv_w4_applicable(const ConvLaunch& c) {
-  return !(c.no_resident & 2) && c.w_split && c.split_unscale > 0.f && c.ksize == 3 && c.stride == 1 && c.pad == 1 && c.cslice == 32 &&
-         c.cin % 32 == 0 && c.cin >= 64 && c.cout_store % W4_BN == 0 && c.cout_pad >= c.cout_store && !c.out_nchw && c.splits == 0 &&
-         ((c.W == 12 && c.H == 12) || (c.W == 6 && c.H == 6)) && c.H == c.Ho && c.W == c.Wo && c.k_pad == 9 * c.cin && c.tile_counter &&
-         c.num_cu > 0 && (size_t)c.n_img * c.H * c.W * c.cin * sizeof(float) < 0x7FFFFF00ull &&
-         (size_t)c.n_img * c.H * c.W * c.cout_store * sizeof(float) < 0x7FFFFF00ull;
+  const bool common = !(c.no_resident & 2) && c.w_split && c.split_unscale > 0.f && c.ksize == 3 && c.stride == 1 && c.pad == 1 && c.cslice == 32 &&
+                      c.cin % 32 == 0 && c.cin >= 64 && c.cout_pad >= c.cout_store && !c.out_nchw && c.splits == 0 && c.H == c.Ho &&
+                      c.W == c.Wo && c.k_pad == 9 * c.cin && c.tile_counter && c.num_cu > 0 &&
+                      (size_t)c.n_img * c.H * c.W * c.cin * sizeof(float) < 0x7FFFFF00ull &&
+                      (size_t)c.n_img * c.H * c.W * c.cout_store * sizeof(float) < 0x7FFFFF00ull;
+  if (!common) return false;
+  if (c.cout_store % 128 == 0) return (c.W == 12 && c.H == 12) || (c.W == 6 && c.H == 6);
+  return !(c.no_resident & 4) && c.cout_store == 64 && c.W == 24 && c.H == 24;
 }
 
 hipError_t launch_conv_w4(const ConvLaunch& c, hipStream_t s) {
   if (!conv_w4_applicable(c)) return hipErrorInvalidValue;
-  return c.W == 12 ? launch_w4_cfg<12, 12>(c, s) : launch_w4_cfg<6, 6>(c, s);
+  if (c.W == 24) return launch_w4_cfg<24, 24, 16, 2>(c, s);
+  return c.W == 12 ? launch_w4_cfg<12, 12, 32, 1>(c, s) : launch_w4_cfg<6, 6, 32, 1>(c, s);
 }
 
 }  // namespace ut

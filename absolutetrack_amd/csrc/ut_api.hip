@@ -644,7 +644,7 @@ int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, fl
   c.k_total = cw.k_total; c.k_pad = cw.k_pad; c.cslice = cw.cslice;
   c.ksize = cw.ksize; c.stride = cw.stride; c.pad = cw.pad;
   c.relu = relu; c.out_nchw = nchw;
-  c.device = h->device; c.num_cu = h->num_cu; c.no_resident = h->resident_weights == 0 ? 3 : h->resident_weights == 2 ? 2 : h->resident_weights == 3 ? 1 : 0;
+  c.device = h->device; c.num_cu = h->num_cu; c.no_resident = h->resident_weights == 0 ? 7 : h->resident_weights == 2 ? 6 : h->resident_weights == 3 ? 1 : h->resident_weights == 4 ? 4 : h->resident_weights == 5 ? 5 : 0;
   int word = 0;
   {
     const unsigned gen = h->word_gen;
@@ -1426,7 +1426,7 @@ int ut_set_block_fusion(ut_handle h, int on) {
 
 int ut_set_resident_weights(ut_handle h, int on) {
   if (!h) return UT_E_INVALID;
-  if (on < 0 || on > 3) return fail(h, UT_E_INVALID, "ut_set_resident_weights: bad argument");
+  if (on < 0 || on > 5) return fail(h, UT_E_INVALID, "ut_set_resident_weights: bad argument");
   h->resident_weights = on;
   return UT_OK;
 }

@@ -162,13 +162,15 @@ int ut_get_split_calibration(ut_handle h, float* out25);
 int ut_set_block_fusion(ut_handle h, int on);
 
 /* Split-fp16 mode only: which kernels take the stride-1 3x3 convolutions of layer2 .. layer4 (A/B switch for tests; 1 = default).
- * csrc/conv_c64k.hip (layer2's 64 -> 64): the weights of an output block resident in registers, two waves per SIMD share the
- *    block and split its K; partial sums are added (slice 0) + (slice 1), so results agree with the chunked kernel's single
- *    running sum to fp32 rounding, not bit for bit.
- * csrc/conv_w4.hip (layer3's 128 -> 128, layer4's 256 -> 256): four waves of 128 x 64, weights global -> registers, the patch split
- *    on its way into LDS, one barrier per 32-channel slice; the chunked kernel's bits.
- * 1: both.  0: neither - the chunked kernel (csrc/conv_split.hip) takes every layer.  2: conv_c64k only.  3: conv_w4 only.
- * (conv_c64k's one-wave-per-SIMD predecessor conv_c64r.hip lives under tools/diag/ with its bit-equality check in split_ab.py.) */
+ * csrc/conv_w4.hip: tiles of whole maps (288 pixels x 128 channels at 12x12 and 6x6, one 24x24 map x 64 channels), four waves of
+ *    288 pixels x 32 channels, weights global -> registers, the patch split on its way into LDS at padded image coordinates, one
+ *    barrier per slice.  At 12x12 / 6x6 the chunked kernel's bits; at 24x24 (16-channel slices) its sum in another order: equal to
+ *    fp32 rounding, deterministic.
+ * csrc/conv_c64k.hip (layer2's 64 -> 64, the form conv_w4 replaced): weights resident in registers, K split across the two waves
+ *    of a SIMD; the chunked kernel's sum to fp32 rounding.
+ * csrc/conv_split.hip: the chunked kernel (every stride-2 3x3 convolution runs through it in any case).
+ * 1: conv_w4 on all three map sizes.  0: the chunked kernel everywhere.  2: conv_c64k on 24x24, chunked elsewhere.  4: conv_w4 at
+ * 12x12 / 6x6, conv_c64k at 24x24.  5: conv_w4 at 12x12 / 6x6, chunked at 24x24.  (3: as 1.) */
 int ut_set_resident_weights(ut_handle h, int on);
 
 /* Latency mode for calls on a handful of crops (the per-frame tracker): convolutions whose launch has far fewer tiles

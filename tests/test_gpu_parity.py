@@ -106,47 +106,51 @@ def test_split_f16_backbone_matches_oracle(engine, split_engine):
 
 
 @pytest.mark.parametrize("n_crops", [1, 5, 37, 300])
-def test_split_f16_resident_weight_kernel_against_the_chunked_kernel(engine, split_engine, n_crops):
-    """Layer2's five stride-1 64 -> 64 convolutions with the weights resident in registers (conv_c64k.hip: two waves per SIMD
-    split K and add their partial sums; bias and residual enter through one wave's accumulators) against conv_split_kernel<256, 64,
-    8, 1, true> on the same tensors: fp32 rounding apart, far inside the split arithmetic's own distance to fp32, and deterministic.
-    1 crop = 4.5 tiles of 128 pixels (fewer tiles than workgroups, a ragged last tile, image borders inside a tile), 5 crops = 22.5,
-    37 = 166.5, 300 crops = 1350 tiles on 256 persistent workgroups (5.3 tiles each: the double-buffered patches wrap, workgroups
-    with five and with six tiles)."""
+def test_split_f16_layer2_kernels_against_the_chunked_kernel(engine, split_engine, n_crops):
+    """Layer2's five stride-1 64 -> 64 convolutions through conv_w4.hip (the default: one 24x24 map x 64 channels per tile, 16-channel
+    slices - the chunked kernel's products summed slice-half by slice-half) and through conv_c64k.hip (weights resident in registers,
+    K split across the two waves of a SIMD) against conv_split_kernel<256, 64, 8, 1, true> on the same tensors: fp32 rounding apart,
+    far inside the split arithmetic's own distance to fp32, and deterministic.  1 crop = one tile (fewer tiles than workgroups), 300
+    crops = 300 tiles on 256 workgroups (the tile queue hands out second tiles; the three patch buffers wrap across tiles)."""
     crops = _dev(synth.synthetic_crops(n_crops, seed=23 + n_crops))
-    pair = split_engine.backbone(crops)
+    w4 = split_engine.backbone(crops)
     try:
-        split_engine.set_resident_weights(0)
+        split_engine.set_resident_weights(5)             # layer3 / layer4 as in the default, layer2 through the chunked kernel
         chunked = split_engine.backbone(crops)
+        split_engine.set_resident_weights(4)             # ... layer2 through conv_c64k
+        pair = split_engine.backbone(crops)
     finally:
         split_engine.set_resident_weights(1)
-    assert torch.isfinite(pair).all()
-    assert torch.equal(split_engine.backbone(crops), pair)           # deterministic
+    assert torch.isfinite(w4).all() and torch.isfinite(pair).all()
+    assert torch.equal(split_engine.backbone(crops), w4)             # deterministic
     fp32 = engine.backbone(crops)
     scale = max(1.0, fp32.abs().max().item())
+    assert (w4 - chunked).abs().max().item() < 2e-6 * scale
     assert (pair - chunked).abs().max().item() < 2e-6 * scale
-    assert (pair - fp32).abs().max().item() < 1e-5 * scale
+    assert (w4 - fp32).abs().max().item() < 1e-5 * scale
 
 
 @pytest.mark.parametrize("n_crops", [1, 2, 5, 37, 300])
 def test_split_f16_four_wave_kernel_has_the_chunked_kernel_bits(engine, split_engine, n_crops):
-    """conv_w4.hip (layer3's 128 -> 128 and layer4's 256 -> 256 convolutions: four waves, each all 288 pixels of a tile x 32 output
+    """conv_w4.hip on layer3's 128 -> 128 and layer4's 256 -> 256 convolutions (four waves, each all 288 pixels of a tile x 32 output
     channels; weights global -> registers, the patch split on its way into LDS at padded image coordinates, one barrier per slice)
     against conv_split_kernel<256, 128, 4, 2, true>: per output element the same products in the same order, so the backbone's
-    features are equal bit for bit.  ut_set_resident_weights(2) routes these layers through the chunked kernel and leaves the rest
-    as it is.  A tile is 2 whole 12x12 maps / 8 whole 6x6 maps: 1 crop = half a tile at 12x12 and an eighth at 6x6 (pixels beyond
-    the tensor inside the only tile), 2 crops = one exact tile at 12x12, 5 and 37 crops = ragged last tiles at both sizes, 300 crops
-    = 150 + 2 x 38 tiles on 256 workgroups (the tile queue hands out second tiles at 6x6)."""
+    features are equal bit for bit (layer2 through the chunked kernel on both sides: ut_set_resident_weights 5 against 0).  A tile is
+    2 whole 12x12 maps / 8 whole 6x6 maps: 1 crop = half a tile at 12x12 and an eighth at 6x6 (pixels beyond the tensor inside the only
+    tile), 2 crops = one exact tile at 12x12, 5 and 37 crops = ragged last tiles at both sizes, 300 crops = 150 + 2 x 38 tiles on 256
+    workgroups (the tile queue hands out second tiles at 6x6)."""
     crops = _dev(synth.synthetic_crops(n_crops, seed=51 + n_crops))
-    got = split_engine.backbone(crops)
     try:
-        split_engine.set_resident_weights(2)             # conv_c64k as in the default, layer3 / layer4 through the chunked kernel
+        split_engine.set_resident_weights(5)
+        got = split_engine.backbone(crops)
+        again = split_engine.backbone(crops)
+        split_engine.set_resident_weights(0)
         chunked = split_engine.backbone(crops)
     finally:
         split_engine.set_resident_weights(1)
     assert torch.isfinite(got).all()
     assert torch.equal(got, chunked)
-    assert torch.equal(split_engine.backbone(crops), got)            # deterministic
+    assert torch.equal(again, got)                                   # deterministic
 
 
 def test_split_f16_fused_layer1_blocks_match_the_two_launch_form(engine, split_engine):
