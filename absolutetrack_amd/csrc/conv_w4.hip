@@ -22,8 +22,9 @@
 //     fp16 pieces and stores the pieces at their padded position - one load, one conversion and two 8-byte LDS stores per k-step,
 //     between the MFMAs; no LDS-DMA, no conversion pass;
 //   * ONE barrier per slice (every 486 MFMAs of a wave): behind it the patch just written is read, the one just read rewritten;
-//   * the epilogue requests a wave's 144 residual values in one go (one memory latency per tile) through one per-lane offset
-//     register and scalar row offsets.
+//   * the epilogue moves residual and output as 16-byte accesses of whole 128-byte rows (each 32 x 32 block goes through 4 KB of
+//     LDS from accumulator order into row order): 1 KB per instruction instead of 256 bytes - the bytes a wave can have in flight
+//     behind its one 6-bit counter are what bounded it; all residual requests of a tile go out before the first value is needed.
 // Every vector-memory operation is a compiler-visible load or store, so the waits are the compiler's; the order of
 // a k-step's instructions is pinned slot by slot (one MFMA per slot).
 // Same tensors, same weight planes and - per output element - the same products in the same order as
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
   constexpr int GSTRIDE = CAP * 16;            // bytes between two 16-byte groups of a row
   constexpr int STAGE = NG * GSTRIDE;          // one slice patch (12x12: 46 KB, 6x6: 52 KB, 24x24 in 16-channel slices: 43 KB)
   constexpr int SLOT = NBUF * STAGE;           // the next tile's index
+  constexpr int EPI = SLOT + 16;               // 4 KB per wave: a 32 x 32 block on its way from accumulator to row order (epilogue)
   static_assert(BM % HW == 0, "a tile is a whole number of maps: every tile has the same padded layout");
   static_assert(BM * NG == W4_NLOAD * 256 && KS % W4_NSET == 0 && (SCH == 32 || SCH == 16) && (WPX == 1 || WPX == 2), "shape");
   static_assert((NG - 2) * GSTRIDE + (2 * PW + 2) * 16 < 65536, "fragment reads: everything but the lane's base fits the immediate offset");
@@ -321,30 +323,52 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
       const unsigned base = ch < p.cout_store ? (unsigned)((tm * BM + wm * W4_WPIX + 4 * fh) * p.cout_store + ch) * 4u : W4_HOOB;
       const unsigned keep_n = base != W4_HOOB ? 0x7FFFFFFFu : 0u;
       if (!ragged) {
+        // A lane's sixteen accumulator registers of a block are one channel of sixteen pixels: stored as they stand, an instruction
+        // moves 256 bytes (two half rows), and with 63 of them in flight a wave keeps 16 KB on its way - a CU then moves ~30 GB/s
+        // whatever the rest of the chip does, and a tile's 294 KB of residual and output took a sixth to a third of its time.
+        // So every block goes through 4 KB of LDS into ROW order - lane l holds pixel 8 t + (l >> 3), channels 4 (l & 7) .. + 3 -
+        // and residual and output move as 16-byte accesses: 1 KB (eight whole 128-byte rows) per instruction, four times the
+        // bytes in flight.  Same arithmetic per element.
         unsigned row_bs = (unsigned)__builtin_amdgcn_readfirstlane((int)row_b);
         asm volatile("" : "+s"(row_bs));
-        float rr[MI][16];
-        if (p.res) {
+        const int ch4 = tn * BN + wco * 32 + 4 * (lane & 7);
+        const unsigned base4 = ch4 < p.cout_store ? (unsigned)((tm * BM + wm * W4_WPIX + (lane >> 3)) * p.cout_store + ch4) * 4u : W4_HOOB;
+        const float4 bb4 = *reinterpret_cast<const float4*>(p.bias + ch4);
+        const unsigned keep4 = base4 != W4_HOOB ? 0x7FFFFFFFu : 0u;
+        // (the residual of five blocks is requested up front, that of block i + 5 at the start of block i - in front of block i's
+        // stores, so that waiting for it never waits for a store younger than five blocks: 96 registers instead of 144)
+        float4 rr[6][4];
 #pragma unroll
-          for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < 5; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-              rr[i][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_rsrc, base, W4_ROW_OFF(i, r), 0));
-        } else {
+          for (int t = 0; t < 4; ++t)
+            rr[i][t] = p.res ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, base4, (unsigned)(32 * i + 8 * t) * row_bs, 0))
+                             : float4{0.f, 0.f, 0.f, 0.f};
+        char* const ex = smem + EPI + wave * 4096;
 #pragma unroll
-          for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i) {
+          if (i + 5 < MI) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rr[i][r] = 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const unsigned o = __float_as_uint(fmaxf(fmaf(acc[i][r], tot_unscale, bb + rr[i][r]), floor_v));
-            unsigned mk;      // (an asm max: as a plain max the compiler builds one reduction tree and keeps every value alive for it)
-            asm volatile("v_and_b32 %0, %2, %3\n\tv_max_u32 %1, %1, %0" : "=&v"(mk), "+v"(out_bits) : "v"(o), "v"(keep_n));
-            __builtin_amdgcn_raw_buffer_store_b32(o, o_rsrc, base, W4_ROW_OFF(i, r), 0);
+            for (int t = 0; t < 4; ++t)
+              rr[(i + 5) % 6][t] = p.res ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, base4, (unsigned)(32 * (i + 5) + 8 * t) * row_bs, 0))
+                                         : float4{0.f, 0.f, 0.f, 0.f};
           }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) *reinterpret_cast<float*>(ex + (8 * (r >> 2) + 4 * fh + (r & 3)) * 128 + fr * 4) = acc[i][r];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float4 a = *reinterpret_cast<const float4*>(ex + (8 * t + (lane >> 3)) * 128 + (lane & 7) * 16);
+            u32x4w o;
+            o.x = __float_as_uint(fmaxf(fmaf(a.x, tot_unscale, bb4.x + rr[i % 6][t].x), floor_v));
+            o.y = __float_as_uint(fmaxf(fmaf(a.y, tot_unscale, bb4.y + rr[i % 6][t].y), floor_v));
+            o.z = __float_as_uint(fmaxf(fmaf(a.z, tot_unscale, bb4.z + rr[i % 6][t].z), floor_v));
+            o.w = __float_as_uint(fmaxf(fmaf(a.w, tot_unscale, bb4.w + rr[i % 6][t].w), floor_v));
+            unsigned mk;      // (an asm max: as a plain max the compiler builds one reduction tree and keeps every value alive for it)
+            asm volatile("v_max3_u32 %0, %2, %3, %4\n\tv_max_u32 %0, %0, %5\n\tv_and_b32 %0, %0, %6\n\tv_max_u32 %1, %1, %0"
+                         : "=&v"(mk), "+v"(out_bits) : "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w), "v"(keep4));
+            __builtin_amdgcn_raw_buffer_store_b128(o, o_rsrc, base4, (unsigned)(32 * i + 8 * t) * row_bs, 0);
+          }
+        }
       } else {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -392,7 +416,7 @@ hipError_t launch_w4_cfg(const ConvLaunch& c, hipStream_t s) {
   const long M = (long)c.n_img * c.H * c.W;
   const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = c.cout_store / BN;
   const int n_tiles = tiles_m * tiles_n;
-  constexpr int lds = (SCH == 32 ? 2 : 3) * (SCH / 4) * w4_cap(BM, WI, HI) * 16 + 16;
+  constexpr int lds = (SCH == 32 ? 2 : 3) * (SCH / 4) * w4_cap(BM, WI, HI) * 16 + 16 + 4 * 4096;
   static std::atomic<unsigned long long> attr_set{0};
   const unsigned long long dev_bit = (c.device >= 0 && c.device < 64) ? 1ull << c.device : 0ull;
   if (!(attr_set.load(std::memory_order_relaxed) & dev_bit) || !dev_bit) {

@@ -48,13 +48,16 @@ head = [("fus0 144->108", 144 * 108), ("fus1 108->72", 108 * 72), ("fus2 72->72"
         ("reg1.conv1 76", 9 * 76 * 76), ("reg1.conv2 76", 9 * 76 * 76)]
 seq += [(nm, 2 * mac * 36 * s) for nm, mac in head]
 
-is_conv = lambda r: any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_c32_patch", "conv_split", "conv_block32", "conv_c64r", "conv_c64k", "conv_c32s2"))
+is_conv = lambda r: any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_c32_patch", "conv_split", "conv_block32", "conv_c64r", "conv_c64k", "conv_c32s2", "conv_w4"))
 
 
 def label(name):
     args = name.split("<")[1].split(">")[0] if "<" in name else ""
     if "conv_split" in name:
         return "split f16 " + "x".join(args.split(", ")[:2])
+    if "conv_w4" in name:
+        a = args.split(", ")
+        return f"split f16 whole maps {a[0]}x{a[1]} x {'128' if a[3] == '1' else '64'} ch, 4 waves"
     if "conv_block32" in name:
         return "fused block 12x16 split f16"
     if "conv_c64r" in name:

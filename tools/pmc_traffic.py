@@ -20,7 +20,7 @@ KIND = sys.argv[6] if len(sys.argv) > 6 else "fp32"
 def covered(name):
     if KIND == "split_f16":
         return ("conv_split_kernel" in name or "conv3x3_c32_patch_kernel<true>" in name or "conv_block32_kernel" in name
-                or "conv_c64r_kernel" in name or "conv_c64k_kernel" in name or "conv_c32s2_kernel" in name)
+                or "conv_c64r_kernel" in name or "conv_c64k_kernel" in name or "conv_w4_kernel" in name or "conv_c32s2_kernel" in name)
     return "conv_igemm" in name or "conv3x3_c32_patch" in name
 
 
