@@ -288,6 +288,8 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
+    // (the tile's bias, for the epilogue: requested here, long before it is needed)
+    const float4 bb4 = *reinterpret_cast<const float4*>(p.bias + (tile % tiles_n) * BN + wco * 32 + 4 * (lane & 7));
     for (int sl = 0; sl < n_slices; ++sl) {
       const bool last_slice = sl == n_slices - 1;
       // the buffers: read this slice's patch, the next slice's (its first fragments are read in this slice's last k-step), the
@@ -333,42 +335,49 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
         asm volatile("" : "+s"(row_bs));
         const int ch4 = tn * BN + wco * 32 + 4 * (lane & 7);
         const unsigned base4 = ch4 < p.cout_store ? (unsigned)((tm * BM + wm * W4_WPIX + (lane >> 3)) * p.cout_store + ch4) * 4u : W4_HOOB;
-        const float4 bb4 = *reinterpret_cast<const float4*>(p.bias + ch4);
         const unsigned keep4 = base4 != W4_HOOB ? 0x7FFFFFFFu : 0u;
         // (the residual of five blocks is requested up front, that of block i + 5 at the start of block i - in front of block i's
-        // stores, so that waiting for it never waits for a store younger than five blocks: 96 registers instead of 144)
+        // stores, so that waiting for it never waits for a store younger than five blocks: 96 registers instead of 144.  Without a
+        // residual the descriptor has no records: the requests return zeros without touching memory.)
         float4 rr[6][4];
 #pragma unroll
         for (int i = 0; i < 5; ++i)
 #pragma unroll
           for (int t = 0; t < 4; ++t)
-            rr[i][t] = p.res ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, base4, (unsigned)(32 * i + 8 * t) * row_bs, 0))
-                             : float4{0.f, 0.f, 0.f, 0.f};
+            rr[i][t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, base4, (unsigned)(32 * i + 8 * t) * row_bs, 0));
+        // half a block (16 pixels x 32 channels, 2 KB) at a time, two regions in turn: the writes of one half go out while the reads
+        // of the half before are on their way back
         char* const ex = smem + EPI + wave * 4096;
+#define W4_EX_WRITE(H)                                                                               \
+        _Pragma("unroll") for (int r = 0; r < 8; ++r)                                                \
+          *reinterpret_cast<float*>(ex + ((H) & 1) * 2048 + (8 * (r >> 2) + 4 * fh + (r & 3)) * 128 + fr * 4) = acc[(H) >> 1][8 * ((H) & 1) + r];
+        W4_EX_WRITE(0)
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          if (i + 5 < MI) {
+        for (int h = 0; h < 2 * MI; ++h) {
+          const int i = h >> 1;
+          if ((h & 1) == 0 && i + 5 < MI) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-              rr[(i + 5) % 6][t] = p.res ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, base4, (unsigned)(32 * (i + 5) + 8 * t) * row_bs, 0))
-                                         : float4{0.f, 0.f, 0.f, 0.f};
+              rr[(i + 5) % 6][t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, base4, (unsigned)(32 * (i + 5) + 8 * t) * row_bs, 0));
           }
+          if (h + 1 < 2 * MI) { W4_EX_WRITE(h + 1) }
 #pragma unroll
-          for (int r = 0; r < 16; ++r) *reinterpret_cast<float*>(ex + (8 * (r >> 2) + 4 * fh + (r & 3)) * 128 + fr * 4) = acc[i][r];
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const float4 a = *reinterpret_cast<const float4*>(ex + (8 * t + (lane >> 3)) * 128 + (lane & 7) * 16);
+          for (int t2 = 0; t2 < 2; ++t2) {
+            const int t = 2 * (h & 1) + t2;
+            const float4 a = *reinterpret_cast<const float4*>(ex + (h & 1) * 2048 + (8 * t2 + (lane >> 3)) * 128 + (lane & 7) * 16);
+            const float4 res = rr[i % 6][t];
             u32x4w o;
-            o.x = __float_as_uint(fmaxf(fmaf(a.x, tot_unscale, bb4.x + rr[i % 6][t].x), floor_v));
-            o.y = __float_as_uint(fmaxf(fmaf(a.y, tot_unscale, bb4.y + rr[i % 6][t].y), floor_v));
-            o.z = __float_as_uint(fmaxf(fmaf(a.z, tot_unscale, bb4.z + rr[i % 6][t].z), floor_v));
-            o.w = __float_as_uint(fmaxf(fmaf(a.w, tot_unscale, bb4.w + rr[i % 6][t].w), floor_v));
+            o.x = __float_as_uint(fmaxf(fmaf(a.x, tot_unscale, bb4.x + res.x), floor_v));
+            o.y = __float_as_uint(fmaxf(fmaf(a.y, tot_unscale, bb4.y + res.y), floor_v));
+            o.z = __float_as_uint(fmaxf(fmaf(a.z, tot_unscale, bb4.z + res.z), floor_v));
+            o.w = __float_as_uint(fmaxf(fmaf(a.w, tot_unscale, bb4.w + res.w), floor_v));
             unsigned mk;      // (an asm max: as a plain max the compiler builds one reduction tree and keeps every value alive for it)
             asm volatile("v_max3_u32 %0, %2, %3, %4\n\tv_max_u32 %0, %0, %5\n\tv_and_b32 %0, %0, %6\n\tv_max_u32 %1, %1, %0"
                          : "=&v"(mk), "+v"(out_bits) : "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w), "v"(keep4));
             __builtin_amdgcn_raw_buffer_store_b128(o, o_rsrc, base4, (unsigned)(32 * i + 8 * t) * row_bs, 0);
           }
         }
+#undef W4_EX_WRITE
       } else {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
