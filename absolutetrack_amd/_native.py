@@ -494,8 +494,8 @@ class HipEngine:
         self._check(self.lib.ut_calibrate_split(self._h, _ptr(crops), crops.shape[0], _stream(self.device)), "ut_calibrate_split")
 
     def split_calibration(self) -> np.ndarray:
-        """The 25 calibrated scale words (stem output, then every block's inner tensor and output) as float32."""
-        out = np.zeros(25, np.float32)
+        """The 33 calibrated scale words (stem output, every block's inner tensor and output, 2 x 4 of the regressors) as float32."""
+        out = np.zeros(33, np.float32)
         self._check(self.lib.ut_get_split_calibration(self._h, out.ctypes.data_as(ctypes.c_void_p)), "ut_get_split_calibration")
         return out
 

@@ -149,26 +149,39 @@ __global__ __launch_bounds__(256) void ftl_out_temporal_in_kernel(HeadArgs a, He
 }
 
 // ---------------------------------------------------------------- temporal output split
+// regin: [S,36,reg_stride], channels 0 .. reg_c - 1 written, reg_c .. reg_stride - 1 zeroed (reg_stride > reg_c: the regressor's
+// tensors padded to the channel count its split-fp16 convolutions run on); out_max (optional): receives the bits of max |regin|
 __global__ __launch_bounds__(256) void temporal_out_kernel(HeadArgs a, const float* __restrict__ t_out,
                                                            const float* __restrict__ skel, int n_skel,
-                                                           float* __restrict__ regin, int reg_c) {
+                                                           float* __restrict__ regin, int reg_c, int reg_stride, unsigned* out_max) {
   UT_RETURN_IF_INVALID(a);
   const int s = blockIdx.x;
   const int slot = (int)a.memory_idx[s];
+  unsigned mx = 0;
   for (int it = threadIdx.x; it < PIX * TC; it += 256) {
     const int p = it / TC, c = it - p * TC;
     if (c >= MEMC + FC) continue;
     const float v = t_out[((size_t)s * PIX + p) * TC + c];
     if (c < MEMC) a.mem[((size_t)slot * PIX + p) * MEMC + c] = v;
-    else regin[((size_t)s * PIX + p) * reg_c + (c - MEMC)] = v;
+    else {
+      regin[((size_t)s * PIX + p) * reg_stride + (c - MEMC)] = v;
+      mx = max(mx, abs_bits(v));
+    }
   }
   if (reg_c > FC) {
     const float* sk = skel + (size_t)(n_skel == 1 ? 0 : s) * PIX * 4;
     for (int it = threadIdx.x; it < PIX * 4; it += 256) {
       const int p = it >> 2, c = it & 3;
-      regin[((size_t)s * PIX + p) * reg_c + FC + c] = sk[it];
+      regin[((size_t)s * PIX + p) * reg_stride + FC + c] = sk[it];
+      mx = max(mx, abs_bits(sk[it]));
     }
   }
+  const int npad = reg_stride - reg_c;
+  for (int it = threadIdx.x; it < PIX * npad; it += 256) {
+    const int p = it / npad, c = it - p * npad;
+    regin[((size_t)s * PIX + p) * reg_stride + reg_c + c] = 0.f;
+  }
+  if (out_max) publish_abs_max(out_max, mx);
 }
 
 // ---------------------------------------------------------------- skeleton encoder
@@ -200,15 +213,15 @@ __global__ __launch_bounds__(192) void skeleton_kernel(const float* __restrict__
 // ---------------------------------------------------------------- pool + output conv + decode
 // Global average pool + the regressor's final 1x1 convolution (commuted: the pool is linear), one block per
 // sample: raw [S,64] (d valid entries, rest 0).
-__global__ __launch_bounds__(128) void pool_matvec_kernel(const float* __restrict__ reg_feat, int reg_c,
+__global__ __launch_bounds__(128) void pool_matvec_kernel(const float* __restrict__ reg_feat, int reg_c, int reg_stride,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           int d, float* __restrict__ raw_out) {
   const int s = blockIdx.x;
   __shared__ float pooled[80];
-  const float* f = reg_feat + (size_t)s * PIX * reg_c;
+  const float* f = reg_feat + (size_t)s * PIX * reg_stride;
   if (threadIdx.x < reg_c) {
     float acc = 0.f;
-    for (int p = 0; p < PIX; ++p) acc += f[p * reg_c + threadIdx.x];
+    for (int p = 0; p < PIX; ++p) acc += f[p * reg_stride + threadIdx.x];
     pooled[threadIdx.x] = acc * (1.0f / 36.0f);
   }
   __syncthreads();
@@ -301,8 +314,8 @@ hipError_t launch_ftl_out_temporal_in(const HeadArgs& a, const HeadBuffers& b, h
   return hipGetLastError();
 }
 hipError_t launch_temporal_out(const HeadArgs& a, const float* t_out, const float* skel, int n_skel,
-                               float* regin, int reg_c, hipStream_t s) {
-  hipLaunchKernelGGL(temporal_out_kernel, dim3(a.n_samples), dim3(256), 0, s, a, t_out, skel, n_skel, regin, reg_c);
+                               float* regin, int reg_c, int reg_stride, unsigned* out_max, hipStream_t s) {
+  hipLaunchKernelGGL(temporal_out_kernel, dim3(a.n_samples), dim3(256), 0, s, a, t_out, skel, n_skel, regin, reg_c, reg_stride, out_max);
   return hipGetLastError();
 }
 hipError_t launch_skeleton(const float* skel_in, const float* w, const float* bias, const float* bn_scale,
@@ -310,10 +323,10 @@ hipError_t launch_skeleton(const float* skel_in, const float* w, const float* bi
   hipLaunchKernelGGL(skeleton_kernel, dim3(n_skel), dim3(192), 0, s, skel_in, w, bias, bn_scale, bn_shift, out);
   return hipGetLastError();
 }
-hipError_t launch_pool_decode(const HeadArgs& a, const float* reg_feat, int reg_c, const float* w,
+hipError_t launch_pool_decode(const HeadArgs& a, const float* reg_feat, int reg_c, int reg_stride, const float* w,
                               const float* bias, int d, float* out_pose, float* out_raw, float* raw_ws, hipStream_t s) {
   float* raw = out_raw ? out_raw : raw_ws;     // [S,64]
-  hipLaunchKernelGGL(pool_matvec_kernel, dim3(a.n_samples), dim3(128), 0, s, reg_feat, reg_c, w, bias, d, raw);
+  hipLaunchKernelGGL(pool_matvec_kernel, dim3(a.n_samples), dim3(128), 0, s, reg_feat, reg_c, reg_stride, w, bias, d, raw);
   hipLaunchKernelGGL(decode_kernel, dim3((a.n_samples + 63) / 64), dim3(64), 0, s, a, raw, d, out_pose);
   return hipGetLastError();
 }

@@ -37,6 +37,7 @@ struct Block {
 
 struct Regressor {
   Block blocks[2];
+  Block blocks_split[2];    // the same convolutions with input and output channels zero-padded to 128: the shape conv_w4.hip takes
   float* w_out = nullptr;   // [D][C] raw (applied after the average pool)
   float* b_out = nullptr;
   int c = 0, d = 0;
@@ -92,6 +93,7 @@ struct ut_context {
   unsigned* calib = nullptr;
   int scale_mode = UT_SPLIT_SCALE_CALIBRATED;
   bool calibrated = false;
+  bool head_calibrated = false;     // ... including the regressor's tensors (needs at least two calibration crops)
   bool calibrating = false;         // the running backbone call is a calibration pass: dynamic scales, maxima merged into calib
   unsigned word_gen = 0;            // bumped by every zeroing of the words: a max word kept across launches is stale after it
   bool block_fusion = true;         // split-fp16 mode: layer1's BasicBlocks as one launch each (ut_set_block_fusion)
@@ -373,6 +375,22 @@ int pack_conv(ut_handle h, ConvW& cw, const float* w, const float* conv_bias, co
   return pack_conv(h, cw, fold_conv(w, conv_bias, bn, cin, cout, ksize * ksize), ksize, stride, cout_store);
 }
 
+constexpr int kRegSplitCh = 128;   // channels of the regressor's tensors when its convolutions run in split-fp16 (zero padded)
+
+// the same convolution with zero rows / columns up to cout x cin channels
+Folded pad_channels(const Folded& f, int cin, int cout) {
+  Folded g;
+  g.cin = cin; g.cout = cout; g.taps = f.taps;
+  g.w.assign((size_t)cout * cin * f.taps, 0.f);
+  g.b.assign(cout, 0.f);
+  for (int o = 0; o < f.cout; ++o) {
+    g.b[o] = f.b[o];
+    for (int c = 0; c < f.cin; ++c)
+      for (int t = 0; t < f.taps; ++t) g.w[((size_t)o * cin + c) * f.taps + t] = f.w[((size_t)o * f.cin + c) * f.taps + t];
+  }
+  return g;
+}
+
 // A BasicBlock's folded convolutions.
 struct FoldedBlock {
   Folded conv1, conv2, ds;
@@ -483,8 +501,17 @@ int take_block(ut_handle h, Cursor& c, Block& b, int cin, int cout, int stride, 
 int take_regressor(ut_handle h, Cursor& c, Regressor& r, int ch, int d) {
   r.c = ch; r.d = d;
   int rc;
-  for (int i = 0; i < 2; ++i)
-    if ((rc = take_block(h, c, r.blocks[i], ch, ch, 1, false))) return rc;
+  for (int i = 0; i < 2; ++i) {
+    FoldedBlock fb;
+    if (!fold_block(c, fb, ch, ch, 1, false)) return fail(h, UT_E_WEIGHTS, "weight blob too short");
+    canonicalise_inner(fb);
+    if ((rc = pack_block(h, r.blocks[i], fb))) return rc;
+    FoldedBlock wide;
+    wide.stride = 1; wide.has_ds = false;
+    wide.conv1 = pad_channels(fb.conv1, kRegSplitCh, kRegSplitCh);
+    wide.conv2 = pad_channels(fb.conv2, kRegSplitCh, kRegSplitCh);
+    if ((rc = pack_block(h, r.blocks_split[i], wide))) return rc;
+  }
   const float* w = c.take((size_t)d * ch);
   const float* b = c.take(d);
   if (!c.ok) return fail(h, UT_E_WEIGHTS, "weight blob too short");
@@ -545,7 +572,7 @@ int ensure_head_ws(ut_handle h, int samples, int n_skel) {
     HIPCHK(h, hipDeviceSynchronize());
     float** ptrs[] = {&h->hb.cat144, &h->hb.f108, &h->hb.f72a, &h->hb.f72b, &h->hb.fused, &h->hb.t92a,
                       &h->hb.t92b, &h->hb.regin, &h->hb.rega, &h->hb.regb};
-    const int ch[] = {144, 108, 72, 72, 72, 92, 92, 76, 76, 76};
+    const int ch[] = {144, 108, 72, 72, 72, 92, 92, kRegSplitCh, kRegSplitCh, kRegSplitCh};
     for (int i = 0; i < 10; ++i) {
       dev_free(h, *ptrs[i]);
       *ptrs[i] = nullptr;
@@ -590,7 +617,7 @@ int ensure_slots(ut_handle h, int slots, hipStream_t s) {
 }
 
 constexpr int kMaxCounters = 4096;
-constexpr int kScaleTensors = 25;
+constexpr int kScaleTensors = 33;      // 25 of the backbone; 25 .. 28 the known-skeleton regressor's input, inner tensors and first block's output, 29 .. 32 the other regressor's
 constexpr int kCalibHeadroom = 4;      // calibrated scale words hold 2^4 x the calibration maximum: inputs up to 32 x that maximum
                                        // (the scale leaves another factor 2 under fp16's 65504) are inside the split's range
 
@@ -708,9 +735,9 @@ int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, fl
 
 // relu(bn2(conv2(relu(bn1(conv1 x)))) + (downsample(x) | x))   lib/models/backbone_resnet.py:56-72
 // x_max: the max word of x's producer (or null); *y_max (optional): the word of the block's output;
-// blk: the block's index in the backbone (x is tensor 2 blk, conv1's output 2 blk + 1), < 0 for the head's blocks
+// x_tid / mid_tid: the scale-tensor ids of x and of conv1's output (backbone block b: 2 b, 2 b + 1; < 0: no split-fp16 path)
 int run_block(ut_handle h, const Block& b, const float* x, float* tmp, float* dsbuf, float* y, int n_img, int H,
-              int W, hipStream_t s, const unsigned* x_max = nullptr, unsigned** y_max = nullptr, int blk = -1) {
+              int W, hipStream_t s, const unsigned* x_max = nullptr, unsigned** y_max = nullptr, int x_tid = -1, int mid_tid = -1) {
   int rc;
   if (y_max) *y_max = nullptr;
   // the words of one block (at most three launches) come from one zeroing: a word handed from conv1 to conv2 is never recycled
@@ -719,7 +746,6 @@ int run_block(ut_handle h, const Block& b, const float* x, float* tmp, float* ds
     if ((rc = begin_call(h, s))) return rc;
     x_max = nullptr;
   }
-  const int x_tid = blk >= 0 ? 2 * blk : -1, mid_tid = blk >= 0 ? 2 * blk + 1 : -1;
   const ScaleRef xs = scale_for(h, x_tid, x_max);
   // layer1 in split-fp16 mode: the whole block in one launch, the intermediate stays in LDS (conv_block32.hip)
   if (h->block_fusion && xs.word && !b.has_ds && b.conv1.w_split && b.conv2.w_split && b.conv1.stride == 1 &&
@@ -847,9 +873,9 @@ int ut_create(int device, const float* blob, size_t n_floats, ut_handle* out) {
   Cursor c{blob, n_floats};
   int rc = UT_OK;
   do {
-    { float* cnt = nullptr; if ((rc = dev_alloc(h, &cnt, 2 * kMaxCounters + 32))) break; h->counters = (unsigned*)cnt;
+    { float* cnt = nullptr; if ((rc = dev_alloc(h, &cnt, 2 * kMaxCounters + 64))) break; h->counters = (unsigned*)cnt;
       h->calib = h->counters + 2 * kMaxCounters;
-      hipError_t e1 = hipMemset(h->calib, 0, 32 * sizeof(unsigned));
+      hipError_t e1 = hipMemset(h->calib, 0, 64 * sizeof(unsigned));
       if (e1 != hipSuccess) { rc = fail(h, UT_E_HIP, "calibration words", e1); break; } }
     { float* st = nullptr; if ((rc = dev_alloc(h, &st, 2))) break; h->status = (int*)st;
       hipError_t e2 = hipMemset(h->status, 0, 2 * sizeof(int));
@@ -1017,7 +1043,7 @@ static int backbone_pass(ut_handle h, const float* crops, const uint8_t* crops_u
     int hw = 48;
     for (int b = 0; b < 5; ++b) {
       float* dst = b == 4 ? h->bufL2 + a24 : y;
-      if ((rc = run_block(h, h->bb[b], x, h->bufH + a48, h->bufD + a24, dst, n, hw, hw, st, xm, &xm, b))) return rc;
+      if ((rc = run_block(h, h->bb[b], x, h->bufH + a48, h->bufD + a24, dst, n, hw, hw, st, xm, &xm, 2 * b, 2 * b + 1))) return rc;
       hw = (hw + 2 - 3) / h->bb[b].conv1.stride + 1;
       float* t = x; x = y; y = t;
     }
@@ -1026,7 +1052,7 @@ static int backbone_pass(ut_handle h, const float* crops, const uint8_t* crops_u
   float *y = h->bufP + a12, *other = h->bufQ + a12;
   int hw = 24;
   for (int b = 5; b < 12; ++b) {
-    if ((rc = run_block(h, h->bb[b], x, h->bufBH + a12, h->bufBD + a12, y, n, hw, hw, st, xm, &xm, b))) return rc;
+    if ((rc = run_block(h, h->bb[b], x, h->bufBH + a12, h->bufBD + a12, y, n, hw, hw, st, xm, &xm, 2 * b, 2 * b + 1))) return rc;
     hw = (hw + 2 - 3) / h->bb[b].conv1.stride + 1;
     x = y;
     float* t = y; y = other; other = t;
@@ -1090,7 +1116,7 @@ static int run_backbone(ut_handle h, const float* crops, const uint8_t* crops_u8
       int hw = 48;
       for (int b = 0; b < 5; ++b) {
         float* dst = b == 4 ? h->bufL2 + (size_t)done * 24 * 24 * 64 : y;
-        if ((rc = run_block(h, h->bb[b], x, h->bufH, h->bufD, dst, n, hw, hw, s, xm, &xm, b))) return rc;
+        if ((rc = run_block(h, h->bb[b], x, h->bufH, h->bufD, dst, n, hw, hw, s, xm, &xm, 2 * b, 2 * b + 1))) return rc;
         hw = (hw + 2 - 3) / h->bb[b].conv1.stride + 1;
         float* t = x; x = y; y = t;
       }
@@ -1104,7 +1130,7 @@ static int run_backbone(ut_handle h, const float* crops, const uint8_t* crops_u8
     int hw = 24;
     unsigned* xm = l2_gen == h->word_gen ? l2_max : nullptr;
     for (int b = 5; b < 12; ++b) {
-      if ((rc = run_block(h, h->bb[b], x, h->bufBH, h->bufBD, y, nb, hw, hw, s, xm, &xm, b))) return rc;
+      if ((rc = run_block(h, h->bb[b], x, h->bufBH, h->bufBD, y, nb, hw, hw, s, xm, &xm, 2 * b, 2 * b + 1))) return rc;
       hw = (hw + 2 - 3) / h->bb[b].conv1.stride + 1;
       x = y;
       float* t = y; y = other; other = t;
@@ -1113,6 +1139,53 @@ static int run_backbone(ut_handle h, const float* crops, const uint8_t* crops_u8
     if ((rc = run_conv(h, h->proj, x, nullptr, feat + (size_t)base * 72 * 36, nb, 6, 6, false, true, s))) return rc;
   }
   return UT_OK;
+}
+
+static int run_head(ut_handle h, const ut::HeadArgs& a, const float* skel, int n_skel, int mode, float* out_pose, float* out_raw,
+                    hipStream_t s);
+
+// Calibration of the regressor's four tensors (per regress mode): the head on the calibration crops' features, paired into two-view
+// samples with canned cameras (f = 130 px, the second view 6 cm to the side), zero temporal memory in scratch state, a zero skeleton.
+static int calibrate_head(ut_handle h, const float* feat, int n_crops, hipStream_t s) {
+  const int S = n_crops / 2;
+  int rc = ensure_head_ws(h, S, 1);
+  if (rc) return rc;
+  // one scratch allocation: [intrinsics 2S x 9 | extrinsics 2S x 16 | skeleton 132 | mem S x 648 | prev_ext S x 16 | pose S x 60 | raw S x 64]
+  // floats, then [sample_range 2S | memory_idx S | hand_idx S] int64, [slot_seen S] int32, [use_memory S] bytes
+  const size_t nf = (size_t)2 * S * 25 + 132 + (size_t)S * (648 + 16 + 60 + 64);
+  const size_t off_i64 = (nf * 4 + 7) / 8 * 8, off_i32 = off_i64 + (size_t)4 * S * 8, off_u8 = off_i32 + (size_t)S * 4, total = off_u8 + S;
+  std::vector<char> host(total, 0);
+  float* f = reinterpret_cast<float*>(host.data());
+  for (int c = 0; c < 2 * S; ++c) {
+    float* k = f + (size_t)c * 9;
+    k[0] = k[4] = 130.f; k[2] = k[5] = 47.5f; k[8] = 1.f;
+    float* x = f + (size_t)2 * S * 9 + (size_t)c * 16;
+    x[0] = x[5] = x[10] = x[15] = 1.f;
+    if (c & 1) x[3] = 0.06f;
+  }
+  long long* i64 = reinterpret_cast<long long*>(host.data() + off_i64);
+  for (int k = 0; k < S; ++k) { i64[2 * k] = 2 * k; i64[2 * k + 1] = 2 * k + 2; i64[2 * S + k] = k; i64[3 * S + k] = k & 1; }
+  void* dv = nullptr;
+  HIPCHK(h, hipMalloc(&dv, total));
+  hipError_t e = hipMemcpyAsync(dv, host.data(), total, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) { (void)hipFree(dv); return fail(h, UT_E_HIP, "calibration descriptors", e); }
+  char* d = static_cast<char*>(dv);
+  float* df = reinterpret_cast<float*>(d);
+  ut::HeadArgs a{};
+  a.feat = feat; a.intrinsics = df; a.extrinsics = df + (size_t)2 * S * 9;
+  const float* skel = df + (size_t)2 * S * 25;
+  a.mem = df + (size_t)2 * S * 25 + 132; a.prev_ext = a.mem + (size_t)S * 648;
+  float* pose = a.prev_ext + (size_t)S * 16;
+  float* raw = pose + (size_t)S * 60;
+  a.sample_range = reinterpret_cast<const int64_t*>(d + off_i64); a.memory_idx = a.sample_range + 2 * S; a.hand_idx = a.memory_idx + S;
+  a.slot_seen = reinterpret_cast<int*>(d + off_i32); a.use_memory = reinterpret_cast<const uint8_t*>(d + off_u8);
+  a.n_samples = S; a.n_crops = 2 * S; a.n_slots = S; a.status = h->status; a.call_error_mask = 0;
+  rc = begin_call(h, s);
+  for (int mode = 0; mode < 2 && !rc; ++mode) rc = run_head(h, a, skel, 1, mode == 0 ? UT_MODE_KNOWN_SKELETON : UT_MODE_UNKNOWN_SKELETON, pose, raw, s);
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(dv);
+  return rc;
 }
 
 // Calibration of the split-fp16 activation scales: `crops` (device fp32 [n,96,96]) through the backbone with the per-launch
@@ -1130,19 +1203,22 @@ static int calibrate_split(ut_handle h, const float* crops, int n, hipStream_t s
   const bool prof = h->profiling;
   h->conv_arith = UT_CONV_SPLIT_F16_ALWAYS; h->lanes = 1; h->profiling = false; h->calibrating = true;
   const bool fusion = h->block_fusion;
-  rc = (int)ut::launch_zero_words(h->calib, 32, s) != 0 ? fail(h, UT_E_HIP, "launch_zero_words") : UT_OK;
+  rc = (int)ut::launch_zero_words(h->calib, 64, s) != 0 ? fail(h, UT_E_HIP, "launch_zero_words") : UT_OK;
   // both launch forms of layer1 / layer2's entry: the separate-launch form (ut_set_block_fusion(h, 0)) has two tensors more
   for (int form = 0; form < 2 && !rc; ++form) {
     h->block_fusion = form == 0;
     rc = run_backbone(h, crops, nullptr, n, feat, s);
   }
   h->block_fusion = fusion;
+  const bool with_head = n >= 2;
+  if (!rc && with_head) rc = calibrate_head(h, feat, n, s);
   h->conv_arith = arith; h->lanes = lanes; h->profiling = prof; h->calibrating = false;
   if (!rc) {
     HIPCHK(h, ut::launch_raise_words(h->calib, kScaleTensors, kCalibHeadroom, s));
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipMemcpy(h->status, saved, sizeof saved, hipMemcpyHostToDevice));
     h->calibrated = true;
+    h->head_calibrated = with_head;
   }
   (void)hipStreamSynchronize(s);
   dev_free(h, feat);
@@ -1177,11 +1253,11 @@ int ut_set_split_scale(ut_handle h, int mode) {
   return UT_OK;
 }
 
-int ut_get_split_calibration(ut_handle h, float* out25) {
-  if (!h || !out25) return fail(h, UT_E_INVALID, "ut_get_split_calibration: null argument");
+int ut_get_split_calibration(ut_handle h, float* out33) {
+  if (!h || !out33) return fail(h, UT_E_INVALID, "ut_get_split_calibration: null argument");
   ON_DEVICE_OF(h);
   HIPCHK(h, hipDeviceSynchronize());
-  HIPCHK(h, hipMemcpy(out25, h->calib, kScaleTensors * sizeof(float), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(out33, h->calib, kScaleTensors * sizeof(float), hipMemcpyDeviceToHost));
   return h->calibrated ? UT_OK : 1;
 }
 
@@ -1227,6 +1303,54 @@ int ut_warp_backbone(ut_handle h, const uint8_t* src, int n_src_images, int src_
   }
   return run_backbone(h, u8 ? nullptr : (const float*)h->crops_ws, u8 ? (const uint8_t*)h->crops_ws : nullptr, n_crops,
                       feat, s);
+}
+
+// The head behind the index checks: FTL, fusion, temporal block, regressor, decode (a.mem / a.prev_ext: the temporal state it
+// reads and writes - the handle's, or scratch during a calibration pass).
+// The regressor's four 3x3 convolutions (76 or 72 channels on the 6x6 map: 80 % of the head's arithmetic) run in the split-fp16
+// arithmetic when the call is large enough to fill the chip with conv_w4's tiles: their tensors are then laid out with 128
+// channels (zeros behind the real ones; zero weight rows and columns), the shape of layer3 at a 6x6 map.
+static int run_head(ut_handle h, const ut::HeadArgs& a, const float* skel, int n_skel, int mode, float* out_pose, float* out_raw,
+                    hipStream_t s) {
+  int rc;
+  const ut::HeadBuffers& b = h->hb;
+  const int S = a.n_samples;
+  h->call_split = false;             // fusion and temporal block: 1x1 convolutions, on the fp32 matrix instruction
+  HIPCHK(h, ut::launch_ftl_in(a, b, s));
+  if ((rc = run_conv(h, h->fus0, b.cat144, nullptr, b.f108, S, 6, 6, true, false, s))) return rc;
+  if ((rc = run_conv(h, h->fus1, b.f108, nullptr, b.f72a, S, 6, 6, true, false, s))) return rc;
+  if ((rc = run_conv(h, h->fus2, b.f72a, nullptr, b.f72b, S, 6, 6, false, false, s))) return rc;
+  HIPCHK(h, ut::launch_ftl_out_temporal_in(a, b, s));
+  if ((rc = run_conv(h, h->tmp[0], b.t92a, nullptr, b.t92b, S, 6, 6, true, false, s))) return rc;
+  if ((rc = run_conv(h, h->tmp[1], b.t92b, nullptr, b.t92a, S, 6, 6, true, false, s))) return rc;
+  if ((rc = run_conv(h, h->tmp[2], b.t92a, nullptr, b.t92b, S, 6, 6, false, false, s))) return rc;
+  const Regressor& reg = mode == UT_MODE_KNOWN_SKELETON ? h->reg_k : h->reg_u;
+  if (mode == UT_MODE_KNOWN_SKELETON)
+    HIPCHK(h, ut::launch_skeleton(skel, h->skel_w, h->skel_b, h->skel_scale, h->skel_shift, b.skel, n_skel, s));
+  // split-fp16 regressor: chosen per call like the backbone's arithmetic (UT_CONV_SPLIT_F16: from 4 x CUs samples = one tile of
+  // 8 samples per CU and wave set), with calibrated scales only once the head has been calibrated
+  const bool head_split = !h->latency_mode && (h->calibrating || h->scale_mode == UT_SPLIT_SCALE_DYNAMIC || h->head_calibrated) &&
+                          (h->conv_arith == UT_CONV_SPLIT_F16_ALWAYS || (h->conv_arith == UT_CONV_SPLIT_F16 && S >= 4 * h->num_cu));
+  const int stride = head_split ? kRegSplitCh : reg.c;
+  const int tid0 = mode == UT_MODE_KNOWN_SKELETON ? 25 : 29;
+  unsigned* in_word = nullptr;
+  if (head_split) {
+    int word = 0;
+    if (h->counter_next + 16 > kMaxCounters && (rc = begin_call(h, s))) return rc;
+    if ((rc = next_launch_word(h, s, &word))) return rc;
+    in_word = h->counters + kMaxCounters + word;
+  }
+  HIPCHK(h, ut::launch_temporal_out(a, b.t92b, b.skel, n_skel, b.regin, reg.c, stride, in_word, s));
+  // two BasicBlocks on the 6x6 map (lib/models/model_utils.py:195-208)
+  h->call_split = head_split;
+  const Block* blocks = head_split ? reg.blocks_split : reg.blocks;
+  unsigned* mid_word = nullptr;
+  rc = run_block(h, blocks[0], b.regin, b.rega, nullptr, b.regb, S, 6, 6, s, in_word, &mid_word, head_split ? tid0 : -1, head_split ? tid0 + 1 : -1);
+  if (!rc) rc = run_block(h, blocks[1], b.regb, b.rega, nullptr, b.regin, S, 6, 6, s, mid_word, nullptr, head_split ? tid0 + 2 : -1, head_split ? tid0 + 3 : -1);
+  h->call_split = false;
+  if (rc) return rc;
+  HIPCHK(h, ut::launch_pool_decode(a, b.regin, reg.c, stride, reg.w_out, reg.b_out, reg.d, out_pose, out_raw, b.rega, s));
+  return UT_OK;
 }
 
 int ut_fuse_temporal_regress(ut_handle h, const float* feat, const float* intrinsics, const float* extrinsics,
@@ -1279,25 +1403,7 @@ int ut_fuse_temporal_regress(ut_handle h, const float* feat, const float* intrin
       return fail(h, UT_E_UNSUPPORTED, "Unsupported: found single-view samples when calibration scale");
   }
   if (n_slots > h->slots_used) h->slots_used = n_slots;
-  const ut::HeadBuffers& b = h->hb;
-  const int S = n_samples;
-  HIPCHK(h, ut::launch_ftl_in(a, b, s));
-  if ((rc = run_conv(h, h->fus0, b.cat144, nullptr, b.f108, S, 6, 6, true, false, s))) return rc;
-  if ((rc = run_conv(h, h->fus1, b.f108, nullptr, b.f72a, S, 6, 6, true, false, s))) return rc;
-  if ((rc = run_conv(h, h->fus2, b.f72a, nullptr, b.f72b, S, 6, 6, false, false, s))) return rc;
-  HIPCHK(h, ut::launch_ftl_out_temporal_in(a, b, s));
-  if ((rc = run_conv(h, h->tmp[0], b.t92a, nullptr, b.t92b, S, 6, 6, true, false, s))) return rc;
-  if ((rc = run_conv(h, h->tmp[1], b.t92b, nullptr, b.t92a, S, 6, 6, true, false, s))) return rc;
-  if ((rc = run_conv(h, h->tmp[2], b.t92a, nullptr, b.t92b, S, 6, 6, false, false, s))) return rc;
-  const Regressor& reg = mode == UT_MODE_KNOWN_SKELETON ? h->reg_k : h->reg_u;
-  if (mode == UT_MODE_KNOWN_SKELETON)
-    HIPCHK(h, ut::launch_skeleton(skel, h->skel_w, h->skel_b, h->skel_scale, h->skel_shift, b.skel, n_skel, s));
-  HIPCHK(h, ut::launch_temporal_out(a, b.t92b, b.skel, n_skel, b.regin, reg.c, s));
-  // two BasicBlocks on the 6x6 map (lib/models/model_utils.py:195-208)
-  if ((rc = run_block(h, reg.blocks[0], b.regin, b.rega, nullptr, b.regb, S, 6, 6, s))) return rc;
-  if ((rc = run_block(h, reg.blocks[1], b.regb, b.rega, nullptr, b.regin, S, 6, 6, s))) return rc;
-  HIPCHK(h, ut::launch_pool_decode(a, b.regin, reg.c, reg.w_out, reg.b_out, reg.d, out_pose, out_raw, b.rega, s));
-  return UT_OK;
+  return run_head(h, a, skel, n_skel, mode, out_pose, out_raw, s);
 }
 
 int ut_reset_memory(ut_handle h) {

@@ -135,7 +135,7 @@ struct HeadBuffers {
   float* fused;     // [S,36,72] cam0-space fused features (input of the temporal block)
   float* t92a;      // [S,36,92] temporal ping
   float* t92b;      // [S,36,92] temporal pong
-  float* regin;     // [S,36,C] regressor input (C = 76 or 72)
+  float* regin;     // [S,36,C] regressor input (C = 76 or 72; 128 with zero channels when its convolutions run in split-fp16)
   float* rega;      // [S,36,C]
   float* regb;      // [S,36,C]
   float* skel;      // [n_skel,36,4]
@@ -221,14 +221,15 @@ hipError_t launch_validate_desc(const HeadArgs& a, hipStream_t s);
 
 hipError_t launch_ftl_in(const HeadArgs& a, const HeadBuffers& b, hipStream_t s);
 hipError_t launch_ftl_out_temporal_in(const HeadArgs& a, const HeadBuffers& b, hipStream_t s);
+// regin [S,36,reg_stride]: channels reg_c .. reg_stride - 1 are zeroed; out_max (optional, zero before the launch): max |regin|
 hipError_t launch_temporal_out(const HeadArgs& a, const float* t_out /*[S,36,92]*/, const float* skel,
-                               int n_skel, float* regin, int reg_c, hipStream_t s);
+                               int n_skel, float* regin, int reg_c, int reg_stride, unsigned* out_max, hipStream_t s);
 hipError_t launch_skeleton(const float* skel_in /*[n_skel,2,22,3]*/, const float* w /*[144][132]*/,
                            const float* bias /*[144]*/, const float* bn_scale /*[4]*/,
                            const float* bn_shift /*[4]*/, float* out /*[n_skel,36,4]*/, int n_skel,
                            hipStream_t s);
 // avgpool(6x6) -> 1x1 conv (C->D) -> decode -> world transform -> pose record [S,60]
-hipError_t launch_pool_decode(const HeadArgs& a, const float* reg_feat /*[S,36,C]*/, int reg_c,
+hipError_t launch_pool_decode(const HeadArgs& a, const float* reg_feat /*[S,36,reg_stride]*/, int reg_c, int reg_stride,
                               const float* w /*[D][C]*/, const float* bias /*[D]*/, int d,
                               float* out_pose, float* out_raw, float* raw_ws /*[S,64] scratch*/, hipStream_t s);
 

@@ -129,14 +129,17 @@ int ut_set_backbone_lanes(ut_handle h, int lanes);
  *                      split for calls of >= 2 x (compute units) crops (512 on MI355X: their 256-row tiles then fill the
  *                      chip down to the 6x6 maps), exact fp32 below.
  *  UT_CONV_SPLIT_F16_ALWAYS  the same for calls of any size (slower on small ones: for tests).
- * The stem, the 1x1 shortcut convolutions, the projection, the head, and every launch in latency mode stay on the fp32
- * instruction in every mode. */
+ * The pose regressor's four 3x3 convolutions (lib/models/model_utils.py:195-208; 76 / 72 channels on the 6x6 map, run on tensors
+ * zero-padded to 128 channels) follow the same choice per ut_fuse_temporal_regress call: split from 4 x (compute units) samples.
+ * The stem, the 1x1 convolutions (shortcuts of layer3 / layer4, projection, fusion, temporal block) and every launch in latency
+ * mode stay on the fp32 instruction in every mode. */
 enum { UT_CONV_FP32 = 0, UT_CONV_SPLIT_F16 = 1, UT_CONV_SPLIT_F16_ALWAYS = 2 };
 int ut_set_conv_arithmetic(ut_handle h, int mode);
 
 /* Where the split-fp16 kernels take a tensor's power-of-two activation scale from.
  *  UT_SPLIT_SCALE_CALIBRATED (default)  one scale word per activation tensor of the backbone (25: the stem's output, every
- *      block's inner tensor and output), fixed per handle: 2^4 x the tensor's largest magnitude over a calibration set.  A crop's
+ *      block's inner tensor and output) and of each pose regressor (4: its input, its blocks' inner tensors, the first block's
+ *      output; calibrated on the calibration crops' features paired into two-view samples under canned cameras), fixed per handle: 2^4 x the tensor's largest magnitude over a calibration set.  A crop's
  *      result then does not depend on what else is in its batch: any batch size, pass size (ut_set_backbone_chunk), lane count or
  *      sharding of a frame set over ranks gives the same bits, as in UT_CONV_FP32 mode.  The calibration set is built in (64
  *      synthetic crops - noise at several contrasts, ramps, bright blobs on a dark ground - generated on the device, the same on
@@ -150,8 +153,9 @@ int ut_set_split_scale(ut_handle h, int mode);
 /* Replace the calibrated scale words by those of `crops` (device fp32 [n_crops,96,96], the tensor ut_backbone takes;
  * n_crops == 0: the built-in set).  Synchronous; results of later split-mode calls change at the 1e-7 level with it. */
 int ut_calibrate_split(ut_handle h, const float* crops, int n_crops, void* stream);
-/* The 25 calibrated scale words as floats (host pointer); returns 1 when the handle has not been calibrated yet. */
-int ut_get_split_calibration(ut_handle h, float* out25);
+/* The 33 calibrated scale words as floats (host pointer; 25 of the backbone, 2 x 4 of the two regressors); returns 1 when the
+ * handle has not been calibrated yet. */
+int ut_get_split_calibration(ut_handle h, float* out33);
 
 /* Split-fp16 mode only: run each BasicBlock of layer1 (32 -> 32 -> 32 channels at 48x48) as ONE launch whose intermediate
  * relu(bn1(conv1 x)) stays in LDS (csrc/conv_block32.hip) instead of two convolution launches with a round trip through HBM

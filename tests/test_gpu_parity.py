@@ -675,7 +675,7 @@ def test_split_f16_calibrated_scales_batch_independence_and_range_guard(engine):
         other.set_conv_arithmetic("split_f16_always")
         cal = eng.split_calibration()
         assert np.array_equal(cal, other.split_calibration()) and np.isfinite(cal).all()
-        assert (cal[:24] > 0).all() and cal[24] == 0            # (the last tensor feeds the projection: no split consumer)
+        assert (cal[:24] > 0).all() and cal[24] == 0 and (cal[25:] > 0).all()      # (tensor 24 feeds the projection: no split consumer)
         whole = eng.backbone(crops)
         assert torch.equal(eng.backbone(crops[7:8]), whole[7:8])
         assert torch.equal(eng.backbone(crops[11:29]), whole[11:29])
