@@ -58,6 +58,7 @@ def main():
                     help="process-group backend for N>1 (nccl = RCCL over xGMI; gloo only to rehearse the multi-process "
                          "control flow on a box with fewer GPUs than ranks: ranks then share devices)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step's launches from one captured hipGraph")
     ap.add_argument("--cropgen-in-step", action="store_true",
                     help="also regenerate the crop cameras from the label poses inside every step (SURVEY 8 f1)")
     args = ap.parse_args()
@@ -117,10 +118,29 @@ def main():
         dist.all_reduce(c, op=dist.ReduceOp.MAX)
         equal = int(c[0]) == -int(c[1])
 
+    # --graph: the launches of one step (resample + backbone, head, FK: ~60 kernels) captured once into a hipGraph and replayed per
+    # step - same kernels, same order, same stream; the gather stays eager
+    graph_state = {}
+
     def one_step():
         if planner is not None:
             planner.refresh(batch)
-        rec = hot.step(batch)
+        if args.graph and planner is None:
+            if "g" not in graph_state:
+                hot.step(batch)                       # (workspace and modes settled by an eager step first)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                side = torch.cuda.Stream(device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    with torch.cuda.graph(g, stream=side):
+                        graph_state["rec"] = hot.step(batch)
+                torch.cuda.current_stream().wait_stream(side)
+                graph_state["g"] = g
+            graph_state["g"].replay()
+            rec = graph_state["rec"]
+        else:
+            rec = hot.step(batch)
         return pipeline.gather_records(rec, world, equal_counts=equal)
 
     def timed_run():

@@ -8,7 +8,7 @@
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 CONV=${CONV:-split_f16}
-O=$R/gpurun_out/profiles_r03_$CONV
+O=$R/gpurun_out/profiles_r04_$CONV
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 python3 $R/bench.py --conv $CONV > $O/bench_stdout.log 2>$O/bench_stderr.log || exit 1
