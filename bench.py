@@ -222,7 +222,7 @@ def main():
                               "(an earlier run of this command, not this process); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024")
         peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split_kind else PEAK_FP32_MFMA_TFLOPS
         roofline = {"bound": "mfma",
-                    "kernel": ("conv_split_kernel (both instantiations) + conv_c64k_kernel (layer2, 64->64) + conv_c32s2_kernel (layer2 entry, 3x3 / 2 + shortcut) + conv_block32_kernel (layer1, one launch per BasicBlock): "
+                    "kernel": ("conv_w4_kernel (stride-1 3x3 of layer2 .. layer4 and of the pose regressor, whole-map tiles) + conv_split_kernel (stride-2 entries of layer3 / layer4) + conv_c32s2_kernel (layer2 entry, 3x3 / 2 + shortcut) + conv_block32_kernel (layer1, one launch per BasicBlock): "
                                "two-piece fp16 splits, 3 products per k on v_mfma_f32_32x32x16_f16" if split_kind else
                                "conv_igemm_kernel (all instantiations) + conv3x3_c32_patch_kernel (layer1)"),
                     "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
