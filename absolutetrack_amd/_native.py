@@ -459,8 +459,10 @@ class HipEngine:
 
     def set_resident_weights(self, kind=1):
         """Split-fp16 mode, A/B switch (include/umetrack_hip.h::ut_set_resident_weights): 1 / True (default) conv_w4.hip on the
-        stride-1 convolutions of layer2 .. layer4; 0 / False the chunked conv_split kernels everywhere; 2 conv_c64k.hip on layer2,
-        chunked elsewhere; 4 conv_w4 on layer3 / layer4 and conv_c64k on layer2; 5 conv_w4 on layer3 / layer4, chunked on layer2."""
+        stride-1 convolutions of layer2 .. layer4 and the stride-2 entries of layer3 / layer4; 0 / False the chunked conv_split
+        kernels everywhere; 6 as 1 but the stride-2 entries through the chunked gather kernel; and, with those through the gather
+        kernel as well: 3 conv_w4 on all stride-1 convolutions, 2 conv_c64k.hip on layer2 and chunked elsewhere, 4 conv_w4 on
+        layer3 / layer4 and conv_c64k on layer2, 5 conv_w4 on layer3 / layer4 and chunked on layer2."""
         self._check(self.lib.ut_set_resident_weights(self._h, int(kind)), "ut_set_resident_weights")
 
     def set_latency_mode(self, on: bool):

@@ -712,8 +712,8 @@ hipError_t launch_conv_split(const ConvLaunch& c, hipStream_t s) {
   if (!conv_split_applicable(c)) return hipErrorInvalidValue;
   if ((size_t)c.n_img * c.H * c.W * c.cin * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
   if ((size_t)c.n_img * c.Ho * c.Wo * c.cout_store * sizeof(float) >= 0x7FFFFF00ull) return hipErrorInvalidValue;
-  // the stride-1 convolutions of layer2 .. layer4 on whole-map tiles: four waves, weights global -> registers, the patch at padded
-  // image coordinates, no chunk synchronisation (conv_w4.hip)
+  // the stride-1 convolutions of layer2 .. layer4 and the stride-2 entries of layer3 / layer4 on whole-map tiles: four waves, weights
+  // global -> registers, the patch at padded image coordinates, no chunk synchronisation (conv_w4.hip)
   if (conv_w4_applicable(c)) return launch_conv_w4(c, s);
   // layer2's 64 -> 64 convolutions with the weights resident in registers (conv_c64k.hip): the form conv_w4 replaced, kept for A/B
   if (conv_c64k_applicable(c)) return launch_conv_c64k(c, s);

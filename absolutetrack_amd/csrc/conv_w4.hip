@@ -64,10 +64,22 @@ __device__ __forceinline__ void w4_split_pair(float a, float b, float s, unsigne
 // WI x HI: the map; SCH: input channels per slice (32: two k-steps per tap; 16: one - half the patch bytes, for maps whose padded
 // tile would not fit twice otherwise); WPX: the tile's pixel halves (1: 288 pixels x 128 output channels, the four waves are its four
 // 32-channel blocks; 2: 576 pixels x 64 output channels, waves (pixel half, channel block))
-template <int WI, int HI, int SCH, int WPX>
+//
+// S2: the 3x3 / stride-2 entries of layer3 and layer4 (64 -> 128 at 24x24 -> 12x12, 128 -> 256 at 12x12 -> 6x6) as PHASE PLANES.
+// WI x HI is then the OUTPUT map; the input's pixels (2Y + py, 2X + px) form four planes of the output's size, and in padded
+// coordinates tap (dy, dx) is a constant row shift in ONE of them: plane (1,1) carries the four corner taps (shifts (-1,-1), (-1,0),
+// (0,-1), (0,0)), (0,1) the two taps dy = 0 (shifts (0,-1), (0,0)), (1,0) the two taps dx = 0 (shifts (-1,0), (0,0)) and (0,0)
+// the centre.  A patch buffer holds TWO planes of 16 input channels where a stride-1 slice holds 32 channels of one (the second
+// plane takes the place of the second k-step half): buffer 0 planes (1,1) + (0,0) - five k-steps -, buffer 1 planes (0,1) + (1,0) -
+// four.  The nine k-steps of a 16-channel slice are one unrolled body with a barrier in front of k-steps 4 and 8; the patch stream
+// is two loads and two conversions per k-step (18 per nine k-steps), every item converted four k-steps after its load, and the
+// buffers never change roles.  Per output element the same products as conv_split_kernel<256, 128, 4, 2, false>, summed plane
+// by plane instead of tap by tap: equal to fp32 rounding, not bit for bit.
+template <int WI, int HI, int SCH, int WPX, bool S2 = false>
 __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles_n, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int MI = W4_MI, PW = WI + 1, PH = HI + 1, HW = WI * HI;
+  static_assert(!S2 || (SCH == 32 && WPX == 1), "phase planes: two 16-channel planes per buffer, four 32-channel blocks per tile");
   constexpr int BM = W4_WPIX * WPX;            // pixels of a tile: whole maps
   constexpr int NCB = 4 / WPX, BN = 32 * NCB;  // 32-channel blocks / output channels of a tile
   constexpr int NG = SCH / 4, NHG = NG / 2;    // 16-byte groups of a patch row: NHG of first pieces, then NHG of remainders
@@ -92,11 +104,11 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
   const int fr = lane & 31, fh = lane >> 5;
 
   const int M = p.n_img * HW;
-  const int n_slices = p.cin / SCH;
+  const int n_slices = p.cin / (S2 ? 16 : SCH);      // S2: 16-channel slices of nine k-steps
   const int n_chunks = p.k_pad / 32;           // 9 per 32 input channels
 
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.in), 0, (int)((size_t)M * p.cin * sizeof(float)), 0x00020000);
+      const_cast<float*>(p.in), 0, (int)((size_t)M * (S2 ? 4 : 1) * p.cin * sizeof(float)), 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.w_split), 0, (int)((size_t)(p.cout_pad / 32) * n_chunks * 4096), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -140,12 +152,28 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
   // per-lane byte offset of pixel t / NG of a tile (pixels behind the tensor are behind the descriptor's range: they load zeros);
   // + j h_step per load, + the slice's channel offset as the scalar offset
 #define W4_H_BASE(TILE) ((unsigned)((((TILE) / tiles_n) * BM + tid / NG) * p.cin + 4 * (tid % NG)) * 4u)
+  // S2: the thread's group t % 8 is plane (t % 8) >> 2, channels 4 (t & 3) .. + 3 of the slice's sixteen; h_in[j]: the input pixel
+  // (2Y, 2X) of its output pixel 32 j + t / 8 inside the tile's maps, po_a / po_b: its plane's pixel in buffer 0 / buffer 1
+  unsigned h_in[S2 ? W4_NLOAD : 1], po_a = 0, po_b = 0, pb1[S2 ? MI : 1];
+  if constexpr (S2) {
+#pragma unroll
+    for (int j = 0; j < W4_NLOAD; ++j) {
+      const int k = RP * j + tid / NG, img = k / HW, rem = k - img * HW, y = rem / WI, x = rem - y * WI;
+      h_in[j] = (unsigned)(((img * 2 * HI + 2 * y) * 2 * WI + 2 * x) * p.cin + 4 * (tid & 3)) * 4u;
+    }
+    const bool second = (tid & 4) != 0;
+    po_a = second ? 0u : (unsigned)((2 * WI + 1) * p.cin) * 4u;
+    po_b = second ? (unsigned)(2 * WI * p.cin) * 4u : (unsigned)p.cin * 4u;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) pb1[i] = pb[i] + (unsigned)STAGE;
+  }
+#define W4S_BASE(TILE) ((unsigned)(((TILE) / tiles_n) * (BM * 4)) * (unsigned)p.cin * 4u)
 
   f32x16w acc[MI];
   u32x4w xp[MI][2];               // pixel fragments (first piece, remainder): ONE set - a fragment of the next k-step is read into its
                                   // registers as soon as this k-step's last MFMA on it has been issued
   u32x4w wf[W4_NSET][2];          // weight fragments (plane 0, plane 1) of the wave's 32 output channels
-  float4 stg[W4_NSTG];            // patch values between their load and their split
+  float4 stg[S2 ? W4_NLOAD : W4_NSTG];      // patch values between their load and their split (S2: item j of either buffer in stg[j])
   const unsigned w_lane = (unsigned)lane * 16u;
 
   // pixel fragment PC (0 first piece, 1 remainder) of block I for k-step half S (SCH == 32) of tap TAP, base register BASE (buffer
@@ -159,6 +187,12 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
     wf[SET][PL] = __builtin_bit_cast(u32x4w, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane, so_, 0)); \
   }
   // k-step Q of slice SL: its tap, its chunk of the weight planes and its half of the chunk
+  // S2, k-step Q = 0 .. 8 of a 16-channel slice: its plane inside its buffer (buffer 1 from k-step 5 on), its shift in padded
+  // coordinates ((dY + 1) * 3 + dX + 1) and the tap of the 3x3 whose weights it takes
+#define W4S_PLANE(Q) ((0x190 >> (Q)) & 1)
+#define W4S_TAPP(Q) ((int)((0x414344310ull >> (4 * (Q))) & 15))
+#define W4S_TAPO(Q) ((int)((0x715348620ull >> (4 * (Q))) & 15))
+#define W4S_BASEOF(Q) ((Q) >= 5 ? pb1 : pb)
 #define W4_TAP(Q) (SCH == 32 ? (Q) >> 1 : (Q))
 #define W4_CHUNK(SL, Q) (SCH == 32 ? (SL) * 9 + ((Q) >> 1) : ((SL) >> 1) * 9 + (Q))
 #define W4_HALF(SL, Q) (SCH == 32 ? (Q) & 1 : (SL) & 1)
@@ -193,19 +227,37 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
   // k-steps and the pixel fragments of the first
   for (int k = tid; k < NBUF * STAGE / 16; k += 256) *reinterpret_cast<u32x4w*>(smem + k * 16) = u32x4w{0, 0, 0, 0};
   __syncthreads();
-  unsigned h_base = W4_H_BASE(tile);
-#pragma unroll
-  for (int a = 0; a < AHEAD; ++a)
-#pragma unroll
-    for (int j = 0; j < W4_NLOAD; ++j) {
-      const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, h_base + (unsigned)j * h_step, (unsigned)(a * SCH * 4), 0));
-      if (a == AHEAD - 1 && KS == 9 && j >= W4_NLOAD - 4) stg[j % W4_NSTG] = v;
-      else W4_SPLIT_STORE(v, (unsigned)(a * STAGE) + h_wa[j])
-    }
+  unsigned h_base = S2 ? 0u : W4_H_BASE(tile);
   unsigned w_row = (unsigned)((tile % tiles_n) * NCB) * (unsigned)n_chunks * 4096u;     // byte offset of the tile column's planes
   unsigned w_row_next = w_row;
+  if constexpr (!S2) {
 #pragma unroll
-  for (int g = 0; g < W4_DIST; ++g) { W4_LOAD_W(g, 0, W4_CHUNK(0, g), W4_HALF(0, g), w_row) W4_LOAD_W(g, 1, W4_CHUNK(0, g), W4_HALF(0, g), w_row) }
+    for (int a = 0; a < AHEAD; ++a)
+#pragma unroll
+      for (int j = 0; j < W4_NLOAD; ++j) {
+        const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, h_base + (unsigned)j * h_step, (unsigned)(a * SCH * 4), 0));
+        if (a == AHEAD - 1 && KS == 9 && j >= W4_NLOAD - 4) stg[j % W4_NSTG] = v;
+        else W4_SPLIT_STORE(v, (unsigned)(a * STAGE) + h_wa[j])
+      }
+#pragma unroll
+    for (int g = 0; g < W4_DIST; ++g) { W4_LOAD_W(g, 0, W4_CHUNK(0, g), W4_HALF(0, g), w_row) W4_LOAD_W(g, 1, W4_CHUNK(0, g), W4_HALF(0, g), w_row) }
+  } else {
+    // the state the steady state has at the start of a slice: buffer 0 complete, item 0 of buffer 1 stored, its items 1 .. 8 loaded
+    const unsigned t0 = W4S_BASE(tile);
+#pragma unroll
+    for (int j = 0; j < W4_NLOAD; ++j) {
+      const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, h_in[j] + po_a + t0, 0, 0));
+      W4_SPLIT_STORE(v, h_wa[j])
+    }
+#pragma unroll
+    for (int j = 0; j < W4_NLOAD; ++j) {
+      const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, h_in[j] + po_b + t0, 0, 0));
+      if (j == 0) W4_SPLIT_STORE(v, (unsigned)STAGE + h_wa[j])
+      else stg[j] = v;
+    }
+#pragma unroll
+    for (int g = 0; g < W4_DIST; ++g) { W4_LOAD_W(g, 0, W4S_TAPO(g), 0, w_row) W4_LOAD_W(g, 1, W4S_TAPO(g), 0, w_row) }
+  }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
@@ -278,6 +330,68 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
         W4_SLOT_BODY(18) W4_SLOT_BODY(19) W4_SLOT_BODY(20) W4_SLOT_BODY(21) W4_SLOT_BODY(22) W4_SLOT_BODY(23) W4_SLOT_BODY(24) W4_SLOT_BODY(25) W4_SLOT_BODY(26) \
       }
 
+  // S2, k-step q of a slice: slots 0, 1 .. 9, 19 .. 26 and 10, 11 as above (the next k-step's fragments come out of buffer 1 from q = 4
+  // on, out of the next slice's buffer 0 at q = 8: both behind that k-step's barrier).  The patch stream, item j of buffer 0 ("a") or
+  // buffer 1 ("b") always through stg[j]:
+  //   converted (slots 12 + 2 n, 13 + 2 n)   q = 0 .. 3: b 2q + 1, b 2q + 2;   q = 4: a 0, a 1, a 2;   q = 5 .. 7: a 2q - 7, a 2q - 6;   q = 8: b 0
+  //   loaded    (slots 18, 21, 24)           q = 0: a 0, a 1, a 2;   q = 1 .. 3: a 2q + 1, a 2q + 2;   q = 4: b 0;   q = 5 .. 8: b 2q - 9, b 2q - 8
+  // - every item four k-steps after its load, an item's register free before the next item j is loaded into it; buffer 1 is written
+  // from the barrier in front of k-step 8 (its last reader) to k-step 3, buffer 0 from the barrier in front of k-step 4 to k-step 7.
+  // The "a" items loaded here and the "b" items from k-step 4 on belong to the NEXT slice (or the next tile's first).
+#define W4S_CV_N(Q) ((Q) == 4 ? 3 : (Q) == 8 ? 1 : 2)
+#define W4S_CV_J(Q, NN) ((Q) < 4 ? 2 * (Q) + 1 + (NN) : (Q) == 4 ? (NN) : (Q) < 8 ? 2 * (Q) - 7 + (NN) : 0)
+#define W4S_CV_DST(Q) (((Q) < 4 || (Q) == 8) ? (unsigned)STAGE : 0u)
+#define W4S_LD_N(Q) ((Q) == 0 ? 3 : (Q) == 4 ? 1 : 2)
+#define W4S_LD_J(Q, NN) ((Q) == 0 ? (NN) : (Q) < 4 ? 2 * (Q) + 1 + (NN) : (Q) == 4 ? 0 : 2 * (Q) - 9 + (NN))
+#define W4S_SLOT_BODY(N)                                                                             \
+        {                                                                                            \
+          if ((N) == 0 && q != 4 && q != 8) { W4_READ_X(MI - 1, 0, W4S_PLANE(q), W4S_TAPP(q), W4S_BASEOF(q)) } \
+          if ((N) >= 1 && (N) <= 9) { W4_READ_X(((N) + 8) % 9, 1, W4S_PLANE(q1), W4S_TAPP(q1), W4S_BASEOF(q1)) } \
+          if ((N) >= 19 && (N) <= 26) { W4_READ_X(((N) + 8) % 9, 0, W4S_PLANE(q1), W4S_TAPP(q1), W4S_BASEOF(q1)) } \
+          if (((N) == 10 || (N) == 11) && qd < 9) { W4_LOAD_W(qd % W4_NSET, (N) & 1, (sl >> 1) * 9 + W4S_TAPO(qd), sl & 1, w_row) } \
+          if (((N) == 10 || (N) == 11) && qd >= 9) { W4_LOAD_W(qd % W4_NSET, (N) & 1, (sl_after >> 1) * 9 + W4S_TAPO(qd - 9), sl_after & 1, row_after) } \
+          if ((N) >= 12 && (N) <= 17 && ((N) & 1) == 0 && ((N) - 12) / 2 < W4S_CV_N(q)) {            \
+            const float4 v_ = stg[W4S_CV_J(q, ((N) - 12) / 2) % 9];                                  \
+            w4_split_pair(v_.x, v_.y, x_scale, cv0, cv1);                                            \
+          }                                                                                          \
+          if ((N) >= 12 && (N) <= 17 && ((N) & 1) == 1 && ((N) - 12) / 2 < W4S_CV_N(q)) {            \
+            const float4 v_ = stg[W4S_CV_J(q, ((N) - 12) / 2) % 9];                                  \
+            unsigned a1_, b1_;                                                                       \
+            w4_split_pair(v_.z, v_.w, x_scale, a1_, b1_);                                            \
+            *reinterpret_cast<u32x2w*>(smem + W4S_CV_DST(q) + h_wa[W4S_CV_J(q, ((N) - 12) / 2) % 9]) = u32x2w{cv0, a1_}; \
+            *reinterpret_cast<u32x2w*>(smem + W4S_CV_DST(q) + h_wa[W4S_CV_J(q, ((N) - 12) / 2) % 9] + NHG * GSTRIDE) = u32x2w{cv1, b1_}; \
+          }                                                                                          \
+          if (((N) == 18 || (N) == 21 || (N) == 24) && ((N) - 18) / 3 < W4S_LD_N(q))                 \
+            stg[W4S_LD_J(q, ((N) - 18) / 3) % 9] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(    \
+                a_rsrc, h_in[W4S_LD_J(q, ((N) - 18) / 3) % 9] + (q < 4 ? hb_a : hb_b), f_soff, 0));  \
+          if ((N) == 16 && q == 1 && sl == 0 && tid == 0) *reinterpret_cast<int*>(smem + SLOT) = grid + ticket; \
+          W4_PIN();                                                                                  \
+          W4_MFMA(ws, N);                                                                            \
+          W4_PIN();                                                                                  \
+        }
+#define W4S_SLICE()                                                                                  \
+      _Pragma("clang loop unroll(full)") for (int q = 0; q < 9; ++q) {                               \
+        const int ws = q % W4_NSET;                                                                  \
+        unsigned cv0 = 0, cv1 = 0;                                                                   \
+        const int q1 = (q + 1) % 9, qd = q + W4_DIST;                                                \
+        if (q == 4 || q == 8) {                                                                      \
+          /* every wave has stored its part of the buffer read next and has read its last fragments of the other one */ \
+          W4_READ_X(MI - 1, 0, W4S_PLANE(q), W4S_TAPP(q), W4S_BASEOF(q))                             \
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+          __builtin_amdgcn_s_barrier();                                                              \
+          asm volatile("" ::: "memory");                                                             \
+          if (q == 8 && sl == 0) {                                                                   \
+            int nv;                                                                                  \
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nv) : "v"(slot_addr) : "memory"); \
+            next_tile = __builtin_amdgcn_readfirstlane(nv);                                          \
+            w_row_next = (unsigned)((next_tile % tiles_n) * NCB) * (unsigned)n_chunks * 4096u;       \
+          }                                                                                          \
+        }                                                                                            \
+        W4S_SLOT_BODY(0) W4S_SLOT_BODY(1) W4S_SLOT_BODY(2) W4S_SLOT_BODY(3) W4S_SLOT_BODY(4) W4S_SLOT_BODY(5) W4S_SLOT_BODY(6) W4S_SLOT_BODY(7) W4S_SLOT_BODY(8) \
+        W4S_SLOT_BODY(9) W4S_SLOT_BODY(10) W4S_SLOT_BODY(11) W4S_SLOT_BODY(12) W4S_SLOT_BODY(13) W4S_SLOT_BODY(14) W4S_SLOT_BODY(15) W4S_SLOT_BODY(16) W4S_SLOT_BODY(17) \
+        W4S_SLOT_BODY(18) W4S_SLOT_BODY(19) W4S_SLOT_BODY(20) W4S_SLOT_BODY(21) W4S_SLOT_BODY(22) W4S_SLOT_BODY(23) W4S_SLOT_BODY(24) W4S_SLOT_BODY(25) W4S_SLOT_BODY(26) \
+      }
+
   for (;;) {
     // the tile after this one: the ticket is taken here, written to LDS by thread 0 in the middle of the tile's first slice and
     // read by everyone behind that slice's barrier (a tile has at least AHEAD + 1 slices)
@@ -290,6 +404,19 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
 
     // (the tile's bias, for the epilogue: requested here, long before it is needed)
     const float4 bb4 = *reinterpret_cast<const float4*>(p.bias + (tile % tiles_n) * BN + wco * 32 + 4 * (lane & 7));
+    if constexpr (S2) {
+      for (int sl = 0; sl < n_slices; ++sl) {
+        const bool last_slice = sl == n_slices - 1;
+        // the patch items loaded during this slice: the next slice's, or the next tile's first (a tile has at least two slices: the
+        // next tile is known from the first slice's second barrier on)
+        const unsigned f_soff = last_slice ? 0u : (unsigned)(sl + 1) * 64u;
+        const unsigned f_tb = W4S_BASE(last_slice ? next_tile : tile);
+        const unsigned hb_a = po_a + f_tb, hb_b = po_b + f_tb;
+        const int sl_after = last_slice ? 0 : sl + 1;
+        const unsigned row_after = last_slice ? w_row_next : w_row;
+        W4S_SLICE()
+      }
+    } else
     for (int sl = 0; sl < n_slices; ++sl) {
       const bool last_slice = sl == n_slices - 1;
       // the buffers: read this slice's patch, the next slice's (its first fragments are read in this slice's last k-step), the
@@ -339,12 +466,15 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
         // (the residual of five blocks is requested up front, that of block i + 5 at the start of block i - in front of block i's
         // stores, so that waiting for it never waits for a store younger than five blocks: 96 registers instead of 144.  Without a
         // residual the descriptor has no records: the requests return zeros without touching memory.)
-        float4 rr[6][4];
+        // (S2: the stride-2 entries have no residual - and eight patch items in flight across the epilogue where stride 1 has none)
+        float4 rr[S2 ? 1 : 6][4];
+        if constexpr (!S2) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i)
+          for (int i = 0; i < 5; ++i)
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
-            rr[i][t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, base4, (unsigned)(32 * i + 8 * t) * row_bs, 0));
+            for (int t = 0; t < 4; ++t)
+              rr[i][t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, base4, (unsigned)(32 * i + 8 * t) * row_bs, 0));
+        }
         // half a block (16 pixels x 32 channels, 2 KB) at a time, two regions in turn: the writes of one half go out while the reads
         // of the half before are on their way back
         char* const ex = smem + EPI + wave * 4096;
@@ -355,7 +485,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
 #pragma unroll
         for (int h = 0; h < 2 * MI; ++h) {
           const int i = h >> 1;
-          if ((h & 1) == 0 && i + 5 < MI) {
+          if (!S2 && (h & 1) == 0 && i + 5 < MI) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
               rr[(i + 5) % 6][t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, base4, (unsigned)(32 * (i + 5) + 8 * t) * row_bs, 0));
@@ -365,7 +495,7 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
           for (int t2 = 0; t2 < 2; ++t2) {
             const int t = 2 * (h & 1) + t2;
             const float4 a = *reinterpret_cast<const float4*>(ex + (h & 1) * 2048 + (8 * t2 + (lane >> 3)) * 128 + (lane & 7) * 16);
-            const float4 res = rr[i % 6][t];
+            const float4 res = S2 ? float4{0.f, 0.f, 0.f, 0.f} : rr[S2 ? 0 : i % 6][t];
             u32x4w o;
             o.x = __float_as_uint(fmaxf(fmaf(a.x, tot_unscale, bb4.x + res.x), floor_v));
             o.y = __float_as_uint(fmaxf(fmaf(a.y, tot_unscale, bb4.y + res.y), floor_v));
@@ -417,45 +547,63 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
 #undef W4_SPLIT_STORE
 #undef W4_SLOT_BODY
 #undef W4_SLICE
+#undef W4S_PLANE
+#undef W4S_TAPP
+#undef W4S_TAPO
+#undef W4S_BASEOF
+#undef W4S_BASE
+#undef W4S_CV_N
+#undef W4S_CV_J
+#undef W4S_CV_DST
+#undef W4S_LD_N
+#undef W4S_LD_J
+#undef W4S_SLOT_BODY
+#undef W4S_SLICE
 }
 
-template <int WI, int HI, int SCH, int WPX>
+template <int WI, int HI, int SCH, int WPX, bool S2 = false>
 hipError_t launch_w4_cfg(const ConvLaunch& c, hipStream_t s) {
   constexpr int BM = W4_WPIX * WPX, BN = 128 / WPX;
-  const long M = (long)c.n_img * c.H * c.W;
+  const long M = (long)c.n_img * c.Ho * c.Wo;
   const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = c.cout_store / BN;
   const int n_tiles = tiles_m * tiles_n;
   constexpr int lds = (SCH == 32 ? 2 : 3) * (SCH / 4) * w4_cap(BM, WI, HI) * 16 + 16 + 4 * 4096;
   static std::atomic<unsigned long long> attr_set{0};
   const unsigned long long dev_bit = (c.device >= 0 && c.device < 64) ? 1ull << c.device : 0ull;
   if (!(attr_set.load(std::memory_order_relaxed) & dev_bit) || !dev_bit) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_w4_kernel<WI, HI, SCH, WPX>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_w4_kernel<WI, HI, SCH, WPX, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_set.fetch_or(dev_bit, std::memory_order_relaxed);
   }
   int grid = c.num_cu;
   if (grid > n_tiles) grid = n_tiles;
-  hipLaunchKernelGGL((conv_w4_kernel<WI, HI, SCH, WPX>), dim3(grid), dim3(256), lds, s, c, tiles_n, n_tiles);
+  hipLaunchKernelGGL((conv_w4_kernel<WI, HI, SCH, WPX, S2>), dim3(grid), dim3(256), lds, s, c, tiles_n, n_tiles);
   return hipGetLastError();
 }
 
 }  // namespace
 
 // (the map sizes are template parameters - taps and padded rows are immediates of the fragment reads: the backbone's 12x12 and 6x6 maps
-// with 128-channel tiles, its 24x24 maps with 64 -> 64 channels as tiles of one whole map)
+// with 128-channel tiles, its 24x24 maps with 64 -> 64 channels as tiles of one whole map; stride 2: the entries of layer3 and layer4,
+// 12x12 and 6x6 OUTPUT maps)
 bool conv_w4_applicable(const ConvLaunch& c) {
-  const bool common = !(c.no_resident & 2) && c.w_split && c.split_unscale > 0.f && c.ksize == 3 && c.stride == 1 && c.pad == 1 && c.cslice == 32 &&
-                      c.cin % 32 == 0 && c.cin >= 64 && c.cout_pad >= c.cout_store && !c.out_nchw && c.splits == 0 && c.H == c.Ho &&
-                      c.W == c.Wo && c.k_pad == 9 * c.cin && c.tile_counter && c.num_cu > 0 &&
+  const bool common = !(c.no_resident & 2) && c.w_split && c.split_unscale > 0.f && c.ksize == 3 && c.pad == 1 && c.cslice == 32 &&
+                      c.cin % 32 == 0 && c.cout_pad >= c.cout_store && !c.out_nchw && c.splits == 0 &&
+                      c.k_pad == 9 * c.cin && c.tile_counter && c.num_cu > 0 &&
                       (size_t)c.n_img * c.H * c.W * c.cin * sizeof(float) < 0x7FFFFF00ull &&
-                      (size_t)c.n_img * c.H * c.W * c.cout_store * sizeof(float) < 0x7FFFFF00ull;
+                      (size_t)c.n_img * c.Ho * c.Wo * c.cout_store * sizeof(float) < 0x7FFFFF00ull;
   if (!common) return false;
+  if (c.stride == 2)      // phase planes
+    return !(c.no_resident & 8) && c.cin >= 32 && c.cout_store % 128 == 0 && c.H == 2 * c.Ho && c.W == 2 * c.Wo && !c.res &&
+           ((c.Wo == 12 && c.Ho == 12) || (c.Wo == 6 && c.Ho == 6));
+  if (c.stride != 1 || c.cin < 64 || c.H != c.Ho || c.W != c.Wo) return false;
   if (c.cout_store % 128 == 0) return (c.W == 12 && c.H == 12) || (c.W == 6 && c.H == 6);
   return !(c.no_resident & 4) && c.cout_store == 64 && c.W == 24 && c.H == 24;
 }
 
 hipError_t launch_conv_w4(const ConvLaunch& c, hipStream_t s) {
   if (!conv_w4_applicable(c)) return hipErrorInvalidValue;
+  if (c.stride == 2) return c.Wo == 12 ? launch_w4_cfg<12, 12, 32, 1, true>(c, s) : launch_w4_cfg<6, 6, 32, 1, true>(c, s);
   if (c.W == 24) return launch_w4_cfg<24, 24, 16, 2>(c, s);
   return c.W == 12 ? launch_w4_cfg<12, 12, 32, 1>(c, s) : launch_w4_cfg<6, 6, 32, 1>(c, s);
 }

@@ -97,7 +97,7 @@ struct ut_context {
   bool calibrating = false;         // the running backbone call is a calibration pass: dynamic scales, maxima merged into calib
   unsigned word_gen = 0;            // bumped by every zeroing of the words: a max word kept across launches is stale after it
   bool block_fusion = true;         // split-fp16 mode: layer1's BasicBlocks as one launch each (ut_set_block_fusion)
-  int resident_weights = 1;         // split-fp16 mode (ut_set_resident_weights): 1 conv_c64k + conv_w4, 0 the chunked kernels, 2 / 3 only one of them off
+  int resident_weights = 1;         // split-fp16 mode (ut_set_resident_weights): 1 conv_w4 wherever it applies, 0 the chunked kernels, 2 .. 6 A/B mixes
   bool call_split = false;          // the running backbone call uses the split-fp16 kernels (decided once per call)
   // index checks: device status words ([0] sticky errors, [1] per call), their pinned host mirror, the duplicate-slot
   // scratch (slots_cap ints, allocated with the temporal state) and the mode (UT_CHECK_*)
@@ -671,7 +671,7 @@ int run_conv(ut_handle h, const ConvW& cw, const float* in, const float* res, fl
   c.k_total = cw.k_total; c.k_pad = cw.k_pad; c.cslice = cw.cslice;
   c.ksize = cw.ksize; c.stride = cw.stride; c.pad = cw.pad;
   c.relu = relu; c.out_nchw = nchw;
-  c.device = h->device; c.num_cu = h->num_cu; c.no_resident = h->resident_weights == 0 ? 7 : h->resident_weights == 2 ? 6 : h->resident_weights == 3 ? 1 : h->resident_weights == 4 ? 4 : h->resident_weights == 5 ? 5 : 0;
+  c.device = h->device; c.num_cu = h->num_cu; { static const int kMask[7] = {15, 0, 14, 9, 12, 13, 8}; c.no_resident = kMask[h->resident_weights]; }      // (ut_kernels.h::ConvLaunch::no_resident)
   int word = 0;
   {
     const unsigned gen = h->word_gen;
@@ -1532,7 +1532,7 @@ int ut_set_block_fusion(ut_handle h, int on) {
 
 int ut_set_resident_weights(ut_handle h, int on) {
   if (!h) return UT_E_INVALID;
-  if (on < 0 || on > 5) return fail(h, UT_E_INVALID, "ut_set_resident_weights: bad argument");
+  if (on < 0 || on > 6) return fail(h, UT_E_INVALID, "ut_set_resident_weights: bad argument");
   h->resident_weights = on;
   return UT_OK;
 }

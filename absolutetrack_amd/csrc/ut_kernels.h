@@ -40,7 +40,8 @@ struct ConvLaunch {
   int num_cu;          // compute units of the device (persistent grid sizing)
   unsigned* tile_counter;   // device word, zero before the launch: dynamic tile queue of the persistent grid
   int no_resident;     // split kernels, A/B tests (ut_set_resident_weights): bit 0 = not conv_c64k.hip, bit 1 = not conv_w4.hip, bit 2 =
-                       // not conv_w4.hip on the 24x24x64 maps (conv_c64k / the chunked conv_split kernels take those layers)
+                       // not conv_w4.hip on the 24x24x64 maps (conv_c64k / the chunked conv_split kernels take those layers), bit 3 = not
+                       // conv_w4.hip's phase-plane form on the stride-2 entries of layer3 / layer4 (the chunked gather kernel takes them)
   int splits;          // > 1 (latency mode): K is cut in `splits` equal chunk ranges, out = [splits][M][cout_store] slabs;
                        // 1 = latency mode without a split (prefers small tiles); 0 = throughput dispatch
 };

@@ -222,7 +222,7 @@ def main():
                               "(an earlier run of this command, not this process); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024")
         peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split_kind else PEAK_FP32_MFMA_TFLOPS
         roofline = {"bound": "mfma",
-                    "kernel": ("conv_w4_kernel (stride-1 3x3 of layer2 .. layer4 and of the pose regressor, whole-map tiles) + conv_split_kernel (stride-2 entries of layer3 / layer4) + conv_c32s2_kernel (layer2 entry, 3x3 / 2 + shortcut) + conv_block32_kernel (layer1, one launch per BasicBlock): "
+                    "kernel": ("conv_w4_kernel (stride-1 3x3 of layer2 .. layer4 and of the pose regressor, and the stride-2 entries of layer3 / layer4 as phase planes: whole-map tiles) + conv_c32s2_kernel (layer2 entry, 3x3 / 2 + shortcut) + conv_block32_kernel (layer1, one launch per BasicBlock): "
                                "two-piece fp16 splits, 3 products per k on v_mfma_f32_32x32x16_f16" if split_kind else
                                "conv_igemm_kernel (all instantiations) + conv3x3_c32_patch_kernel (layer1)"),
                     "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
@@ -305,7 +305,10 @@ def main():
                        "collective": "one all_gather_into_tensor of the [S_local,123] records per step" if world > 1 else None,
                        "ranks": ranks,
                        "outputs_finite": finite},
-            "conv_arithmetic": args.conv, "split_f16_check": split_check, "exact_fp32_mode": fp32_mode,
+            "conv_arithmetic": args.conv,
+            "split_scale": ("calibrated: fixed per-tensor powers of two from the built-in 64-crop calibration pass, 2^4 headroom, range-guarded"
+                            if split_kind else None),
+            "split_f16_check": split_check, "exact_fp32_mode": fp32_mode,
             "parity_batched_vs_oracle": batched,
             "roofline": roofline, "roofline_exact_fp32_mode": roofline_fp32, "cpu_baseline": cpu,
             "mpjpe_delta_mm": None if parity is None else parity["mpjpe_delta_mm"], "parity_recording_00": parity,

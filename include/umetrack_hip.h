@@ -165,16 +165,18 @@ int ut_get_split_calibration(ut_handle h, float* out33);
  * an fp32 launch; the shortcut then runs in the split arithmetic too).  0 is for A/B tests. */
 int ut_set_block_fusion(ut_handle h, int on);
 
-/* Split-fp16 mode only: which kernels take the stride-1 3x3 convolutions of layer2 .. layer4 (A/B switch for tests; 1 = default).
+/* Split-fp16 mode only: which kernels take the 3x3 convolutions of layer2 .. layer4 (A/B switch for tests; 1 = default).
  * csrc/conv_w4.hip: tiles of whole maps (288 pixels x 128 channels at 12x12 and 6x6, one 24x24 map x 64 channels), four waves of
  *    288 pixels x 32 channels, weights global -> registers, the patch split on its way into LDS at padded image coordinates, one
- *    barrier per slice.  At 12x12 / 6x6 the chunked kernel's bits; at 24x24 (16-channel slices) its sum in another order: equal to
- *    fp32 rounding, deterministic.
+ *    barrier per slice.  Stride 1 at 12x12 / 6x6: the chunked kernel's bits; at 24x24 (16-channel slices) and on the stride-2
+ *    entries of layer3 / layer4 (four phase planes of the input, summed plane by plane) its sum in another order: equal to fp32
+ *    rounding, deterministic.
  * csrc/conv_c64k.hip (layer2's 64 -> 64, the form conv_w4 replaced): weights resident in registers, K split across the two waves
  *    of a SIMD; the chunked kernel's sum to fp32 rounding.
- * csrc/conv_split.hip: the chunked kernel (every stride-2 3x3 convolution runs through it in any case).
- * 1: conv_w4 on all three map sizes.  0: the chunked kernel everywhere.  2: conv_c64k on 24x24, chunked elsewhere.  4: conv_w4 at
- * 12x12 / 6x6, conv_c64k at 24x24.  5: conv_w4 at 12x12 / 6x6, chunked at 24x24.  (3: as 1.) */
+ * csrc/conv_split.hip: the chunked kernels (layer2's stride-2 entry is csrc/conv_c32s2.hip in any case).
+ * 1: conv_w4 wherever it applies.  0: the chunked kernels everywhere.  6: as 1 with the stride-2 entries through the chunked gather
+ * kernel.  With those through the gather kernel as well - 2: conv_c64k on 24x24, chunked elsewhere.  4: conv_w4 at 12x12 / 6x6,
+ * conv_c64k at 24x24.  5: conv_w4 at 12x12 / 6x6, chunked at 24x24.  3: conv_w4 on the stride-1 convolutions of all three sizes. */
 int ut_set_resident_weights(ut_handle h, int on);
 
 /* Latency mode for calls on a handful of crops (the per-frame tracker): convolutions whose launch has far fewer tiles

@@ -153,6 +153,32 @@ def test_split_f16_four_wave_kernel_has_the_chunked_kernel_bits(engine, split_en
     assert torch.equal(again, got)                                   # deterministic
 
 
+@pytest.mark.parametrize("n_crops", [1, 2, 5, 37, 300])
+def test_split_f16_phase_plane_entries_against_the_gather_kernel(engine, split_engine, n_crops):
+    """The stride-2 3x3 entries of layer3 (64 -> 128, 24x24 -> 12x12) and layer4 (128 -> 256, 12x12 -> 6x6) through conv_w4.hip's
+    phase-plane form (the default: the input's four (row parity, column parity) planes at padded coordinates of the OUTPUT map, two
+    16-channel planes per patch buffer, products summed plane by plane) against conv_split_kernel<256, 128, 4, 2, false> (gathers
+    tap by tap) on the same tensors (ut_set_resident_weights 1 against 6): the same products in another order - fp32 rounding
+    apart, far inside the split arithmetic's own distance to fp32 - and deterministic.  1 crop = half / an eighth of a tile (pixels
+    beyond the tensor inside the only tile, and a next tile that does not exist), 2 crops = one exact tile at 12x12, 5 and 37 =
+    ragged last tiles, 300 = 150 + 2 x 38 tiles on 256 workgroups (second tiles from the queue)."""
+    crops = _dev(synth.synthetic_crops(n_crops, seed=77 + n_crops))
+    planes = split_engine.backbone(crops)
+    try:
+        split_engine.set_resident_weights(6)
+        gather = split_engine.backbone(crops)
+    finally:
+        split_engine.set_resident_weights(1)
+    assert torch.isfinite(planes).all()
+    assert torch.equal(split_engine.backbone(crops), planes)         # deterministic
+    assert not torch.equal(planes, gather)                           # a different kernel did run
+    fp32 = engine.backbone(crops)
+    scale = max(1.0, fp32.abs().max().item())
+    assert (planes - gather).abs().max().item() < 2e-6 * scale
+    assert (planes - fp32).abs().max().item() < 1e-5 * scale
+    split_engine.poll_status()
+
+
 def test_split_f16_fused_layer1_blocks_match_the_two_launch_form(engine, split_engine):
     """conv_block32.hip (layer1's BasicBlocks as one launch each, the intermediate in LDS) against the same arithmetic as two
     convolution launches per block: the forms differ only in the intermediate's power-of-two scale (a bound there, the
@@ -347,8 +373,24 @@ def _run_steps(engine, known, want_raw=True):
 
 @pytest.mark.parametrize("known", [True, False])
 def test_split_f16_model_matches_reference_goldens(split_engine, golden_dir, known):
-    """The reference's own outputs (tests/golden/model_*.npz), same tolerances, with the backbone on the split-fp16 kernel."""
+    """The reference's own outputs (tests/golden/model_*.npz), same tolerances, with the backbone's and the pose regressor's 3x3
+    convolutions on the split-fp16 kernels (calibrated scales, the default)."""
     test_model_matches_reference_goldens(split_engine, golden_dir, known)
+    split_engine.poll_status()
+
+
+@pytest.mark.parametrize("known", [True, False])
+def test_split_f16_dynamic_scales_match_reference_goldens(golden_dir, known):
+    """The same with UT_SPLIT_SCALE_DYNAMIC: every split launch - backbone and regressor - scales by the largest magnitude its
+    producer stored in this call."""
+    eng = _native.HipEngine(synth.synthetic_state_dict(0), DEV)
+    try:
+        eng.set_split_scale("dynamic")
+        eng.set_conv_arithmetic("split_f16_always")
+        test_model_matches_reference_goldens(eng, golden_dir, known)
+        eng.poll_status()
+    finally:
+        eng.close()
 
 
 @pytest.mark.parametrize("known", [True, False])

@@ -38,7 +38,7 @@ extern "C" int conv_diag2(const float* in, const float* w, const void* w_split, 
   (void)hipMemsetAsync(cnt, 0, 4, 0);
   c.tile_counter = cnt;
   if (!mode) c.w_split = nullptr;
-  c.no_resident = mode == 3 ? 7 : mode == 4 ? 6 : 0;      // 3: the chunked kernels only, 4: conv_c64k where applicable, no conv_w4      // 1: conv_c64k where applicable, 2: conv_c64r (lab), 3: the chunked kernel
+  c.no_resident = mode == 3 ? 15 : mode == 4 ? 14 : 0;      // 3: the chunked kernels only, 4: conv_c64k where applicable, no conv_w4      // 1: conv_c64k where applicable, 2: conv_c64r (lab), 3: the chunked kernel
   if (mode == 2 && ut::conv_c64r_applicable(c)) return (int)ut::launch_conv_c64r(c, 0);
 #ifdef C64_STAMPS
   if (!g_dbg) { (void)hipMalloc((void**)&g_dbg, 256 * 8 * 8); (void)hipMemset(g_dbg, 0, 256 * 8 * 8); }

@@ -5,7 +5,9 @@ of a COPY.
       W4_ABL=nostore,nores,nowload,nopatch,noxread,nobarrier   timing-only ablations (wrong numbers)
       W4_ALT_SRCS=<path>,<path>                               other versions of conv_w4.hip (checked bit for bit, timed as alt:<file>)
       W4_STAMPS=1                                             s_memtime stamps of every workgroup's fourth tile (wave 0)
-      AB_ROUNDS=<n>                                           timing rounds (default 10; random order, a lead-in per case)"""
+      AB_ROUNDS=<n>                                           timing rounds (default 10; random order, a lead-in per case)
+      W4_STRIDE=2                                             the phase-plane form (hw = the INPUT map; no residual; against the chunked
+                                                              gather kernel and the fp32-instruction kernel: sums in another order)"""
 import ctypes
 import os
 import random
@@ -19,6 +21,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(ROOT, "absolutetrack_amd", "csrc")
 cin, cout, hw, n_img = (int(a) for a in sys.argv[1:5])
+stride = int(os.environ.get("W4_STRIDE", "1"))
+ho = hw // stride
 
 ABL = {
     "nostore": [("            __builtin_amdgcn_raw_buffer_store_b32(o, o_rsrc, off, 0, 0);", "            if (p.k_pad < 0) __builtin_amdgcn_raw_buffer_store_b32(o, o_rsrc, off, 0, 0);")],
@@ -45,6 +49,14 @@ STAMP_PATCHES = [
      "      for (int i = 0; i < 8; ++i) d[i] = st_[i];\n    }\n    ++n_done;\n    if ((unsigned)next_tile >= (unsigned)n_tiles) break;\n"),
 ]
 
+# the phase-plane form: stamps behind slices 0, 1, n - 2, n - 1 and behind the epilogue
+STAMP_PATCHES_S2 = [
+    STAMP_PATCHES[0],
+    ("  for (;;) {\n    // the tile after this one", "  unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};\n  int n_done = 0;\n  for (;;) {\n    " + st(0) + "\n    // the tile after this one"),
+    ("        W4S_SLICE()\n", "        W4S_SLICE()\n        if (sl == 0) " + st(1) + "\n        if (sl == 1) " + st(2) + "\n        if (sl == n_slices - 2) " + st(3) + "\n        if (sl == n_slices - 1) " + st(4) + "\n"),
+    (STAMP_PATCHES[4][0], STAMP_PATCHES[4][1].replace(st(7), st(5))),
+]
+
 
 def patched(name, patches, src=None):
     text = open(src or os.path.join(CSRC, "conv_w4.hip")).read()
@@ -67,7 +79,7 @@ def build(name, w4=None, flags=()):
 
 stamps = bool(os.environ.get("W4_STAMPS"))
 stamp_src = os.environ.get("W4_STAMPS") if os.path.exists(os.environ.get("W4_STAMPS", "")) else None      # W4_STAMPS=<path>: stamps of that source
-lib = build("stamps", patched("stamps", STAMP_PATCHES, stamp_src), flags=["-DC64_STAMPS"]) if stamps else build("product")
+lib = build("stamps", patched("stamps", STAMP_PATCHES if stride == 1 else STAMP_PATCHES_S2, stamp_src), flags=["-DC64_STAMPS"]) if stamps else build("product")
 vlibs = {}
 for nm in [q for q in os.environ.get("W4_ABL", "").split(",") if q]:
     vlibs["abl:" + nm] = build("abl_" + nm.replace("+", "_"), patched(nm.replace("+", "_"), sum((ABL[x] for x in nm.split("+")), [])))
@@ -88,20 +100,20 @@ wp = torch.zeros(cout_pad, k_total)
 wp[:cout] = w_oihw.reshape(cout, cin // 32, 32, 9).permute(0, 1, 3, 2).reshape(cout, k_total)
 bias = torch.zeros(cout_pad)
 bias[:cout] = torch.randn(cout) * 0.1
-res = torch.rand(n_img, hw, hw, cout, device=dev)
+res = torch.rand(n_img, ho, ho, cout, device=dev) if stride == 1 else None
 split = np.zeros(2 * cout_pad * k_total, np.uint16)
 assert lib.split_pack(wp.numpy().ctypes.data_as(ctypes.c_void_p), cout_pad, k_total, split.ctypes.data_as(ctypes.c_void_p)) == 0
 for l in list(vlibs.values()) + list(alts.values()):
     assert l.split_pack(wp.numpy().ctypes.data_as(ctypes.c_void_p), cout_pad, k_total, split.ctypes.data_as(ctypes.c_void_p)) == 0
 w_d, b_d = wp.to(dev), bias.to(dev)
 s_d = torch.from_numpy(split.view(np.int16)).to(dev)
-out = torch.empty(n_img, hw, hw, cout, device=dev)
+out = torch.empty(n_img, ho, ho, cout, device=dev)
 
 
 def run(mode, l=lib):
     rc = l.conv_diag2(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(w_d.data_ptr()), ctypes.c_void_p(s_d.data_ptr()),
-                      ctypes.c_void_p(b_d.data_ptr()), ctypes.c_void_p(res.data_ptr()), ctypes.c_void_p(out.data_ptr()),
-                      n_img, hw, cin, cout, 3, 1, 1, mode)
+                      ctypes.c_void_p(b_d.data_ptr()), ctypes.c_void_p(res.data_ptr() if res is not None else None), ctypes.c_void_p(out.data_ptr()),
+                      n_img, hw, cin, cout, 3, stride, 1, mode)
     assert rc == 0, rc
 
 
@@ -111,6 +123,14 @@ if stamps:
     assert lib.conv_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
     t = buf.reshape(256, 8).astype(np.int64)
     t = t[t[:, 0] > 0]
+    if stride != 1:
+        n_sl = cin // 16
+        names = ["slice 0", "slice 1", f"slices 2 .. {n_sl - 2} ({n_sl - 3} of them)", f"slice {n_sl - 1}", "epilogue"]
+        d = np.diff(t[:, :6], axis=1)
+        for i, nm in enumerate(names):
+            print(f"   {nm:40s} median {int(np.median(d[:, i])):7d}  p10 {int(np.percentile(d[:, i], 10)):7d}  p90 {int(np.percentile(d[:, i], 90)):7d}")
+        print(f"   whole tile median {int(np.median(t[:, 5] - t[:, 0]))} (s_memtime ticks; a slice is 243 MFMAs per wave = 7,776 cycles of the matrix pipe)")
+        sys.exit(0)
     d = np.diff(t, axis=1)
     names = ["first slice, k-steps 0 .. 8", "first slice, k-steps 9 .. 17", "second slice", "slices 2 .. n-2", "last slice, k-steps 0 .. 8 (fetches the next tile's patch)",
              "last slice, k-steps 9 .. 17", "epilogue"]
@@ -126,13 +146,20 @@ ref = out.clone()
 out.fill_(float("nan"))
 run(1)
 torch.cuda.synchronize()
-print(f"conv_w4 == chunked HALO bit for bit: {bool(torch.equal(out, ref))}   max |difference| {float((out - ref).abs().max()):.3e} (|out| max {float(ref.abs().max()):.2f})")
+print(f"conv_w4 == chunked bit for bit: {bool(torch.equal(out, ref))}   max |difference| {float((out - ref).abs().max()):.3e} (|out| max {float(ref.abs().max()):.2f})")
+if stride != 1:
+    got = out.clone()
+    out.fill_(float("nan"))
+    run(0)
+    torch.cuda.synchronize()
+    print(f"   against the fp32-instruction kernel: conv_w4 {float((got - out).abs().max()):.3e}, chunked {float((ref - out).abs().max()):.3e}; "
+          f"against torch conv2d (fp64): {float((got.double() - torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w_oihw.to(dev).double(), bias[:cout].to(dev).double(), stride=stride, padding=1).relu().permute(0, 2, 3, 1)).abs().max()):.3e}")
 for nm, l in alts.items():
     out.fill_(float("nan"))
     run(1, l)
     torch.cuda.synchronize()
     print(f"{nm} == chunked bit for bit: {bool(torch.equal(out, ref))}")
-flops = 2.0 * n_img * hw * hw * cout * k_total
+flops = 2.0 * n_img * ho * ho * cout * k_total
 cases = [("conv_w4", 1, lib), ("chunked HALO", 3, lib)] + ([("conv_c64k", 4, lib)] if cout == 64 else []) + [(v, 1, l) for v, l in vlibs.items()] + [(v, 1, l) for v, l in alts.items()]
 times = {name: [] for name, _m, _l in cases}
 random.seed(1)

@@ -57,6 +57,8 @@ def label(name):
         return "split f16 " + "x".join(args.split(", ")[:2])
     if "conv_w4" in name:
         a = args.split(", ")
+        if len(a) > 4 and a[4] == "true":
+            return f"split f16 phase planes -> {a[0]}x{a[1]} x 128 ch, 4 waves"
         return f"split f16 whole maps {a[0]}x{a[1]} x {'128' if a[3] == '1' else '64'} ch, 4 waves"
     if "conv_block32" in name:
         return "fused block 12x16 split f16"

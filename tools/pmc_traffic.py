@@ -47,7 +47,7 @@ fetch, nf = per_launch(sys.argv[1], "FETCH_SIZE")
 write, nw = per_launch(sys.argv[2], "WRITE_SIZE")
 out = {
     "conv_arithmetic": KIND,
-    "kernel": ("conv_w4_kernel (stride-1 3x3 of layer2 .. layer4 and of the pose regressor) + conv_split_kernel (stride-2 entries of layer3 / layer4) + conv_c32s2_kernel (layer2 entry: 3x3 / 2 + shortcut) + conv_block32_kernel (layer1, one launch per BasicBlock)" if KIND == "split_f16" else
+    "kernel": ("conv_w4_kernel (stride-1 3x3 of layer2 .. layer4 and of the pose regressor, stride-2 entries of layer3 / layer4 as phase planes) + conv_c32s2_kernel (layer2 entry: 3x3 / 2 + shortcut) + conv_block32_kernel (layer1, one launch per BasicBlock)" if KIND == "split_f16" else
                "conv_igemm_kernel (all instantiations) + conv3x3_c32_patch_kernel"), "label": sys.argv[4] if len(sys.argv) > 4 else "",
     "launches_fetch_pass": nf, "launches_write_pass": nw,
     "FETCH_SIZE_KiB_per_launch_raw": fetch / max(nf, 1), "WRITE_SIZE_KiB_per_launch": write / max(nw, 1),
