@@ -50,7 +50,9 @@ constexpr int W4_DIST = 2;                     // weight fragments are loaded th
 constexpr int W4_NSET = W4_DIST + 1;           // (9 and 18 k-steps % W4_NSET == 0: the register sets line up across slices)
 constexpr unsigned W4_HOOB = 0x80000000u;      // out-of-range offset that stays out of range with a scalar offset added
 static_assert(9 % W4_NSET == 0, "the register sets of the weight fragments line up across slices");
-// padded rows of a slice patch: the tile's maps, each (H + 1)(W + 1) rows, + W + 2 rows either side, rounded up
+// padded rows of a slice patch: the tile's maps, each (H + 1)(W + 1) rows, + W + 2 rows either side, rounded up.  (The 16-byte groups of
+// a pixel are then a multiple of 256 bytes apart; an odd multiple of 128 - which spreads a wave's patch stores over all banks -
+// measured the same on every shape: tools/diag/w4_ab.py, W4_ALT_SRCS.)
 constexpr int w4_cap(int pixels, int wi, int hi) { return ((pixels / (wi * hi)) * (hi + 1) * (wi + 1) + 2 * (wi + 2) + 15) / 16 * 16; }
 
 // the pieces of a * s and b * s for a power of two s (conv_split.hip::split_pair_scaled)
@@ -331,13 +333,17 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
       }
 
   // S2, k-step q of a slice: slots 0, 1 .. 9, 19 .. 26 and 10, 11 as above (the next k-step's fragments come out of buffer 1 from q = 4
-  // on, out of the next slice's buffer 0 at q = 8: both behind that k-step's barrier).  The patch stream, item j of buffer 0 ("a") or
+  // on, out of the next slice's buffer 0 at q = 8).  The barrier of k-steps 4 and 8 sits in front of slot 9 - the k-step's own last
+  // fragment was read nine MFMAs earlier, so the barrier waits for the other waves and for nothing else - with the remainder pieces
+  // of the next k-step read in slots 10 .. 18.  The patch stream, item j of buffer 0 ("a") or
   // buffer 1 ("b") always through stg[j]:
-  //   converted (slots 12 + 2 n, 13 + 2 n)   q = 0 .. 3: b 2q + 1, b 2q + 2;   q = 4: a 0, a 1, a 2;   q = 5 .. 7: a 2q - 7, a 2q - 6;   q = 8: b 0
-  //   loaded    (slots 18, 21, 24)           q = 0: a 0, a 1, a 2;   q = 1 .. 3: a 2q + 1, a 2q + 2;   q = 4: b 0;   q = 5 .. 8: b 2q - 9, b 2q - 8
+  //   converted (slots 10 + 4 n .. 13 + 4 n)   q = 0 .. 3: b 2q + 1, b 2q + 2;   q = 4: a 0, a 1, a 2;   q = 5 .. 7: a 2q - 7, a 2q - 6;   q = 8: b 0
+  //   loaded    (slots 22, 23, 24)             q = 0: a 0, a 1, a 2;   q = 1 .. 3: a 2q + 1, a 2q + 2;   q = 4: b 0;   q = 5 .. 8: b 2q - 9, b 2q - 8
   // - every item four k-steps after its load, an item's register free before the next item j is loaded into it; buffer 1 is written
-  // from the barrier in front of k-step 8 (its last reader) to k-step 3, buffer 0 from the barrier in front of k-step 4 to k-step 7.
-  // The "a" items loaded here and the "b" items from k-step 4 on belong to the NEXT slice (or the next tile's first).
+  // from the barrier of k-step 8 (its last reader) to k-step 3, buffer 0 from the barrier of k-step 4 to k-step 7.  The "a" items
+  // loaded here and the "b" items from k-step 4 on belong to the NEXT slice (or the next tile's first).  (Measured and not kept: every
+  // item nine k-steps after its load, 18 registers; the weight fragments eight k-steps ahead, nine sets - both the same time.
+  // Without the patch loads the launch is 11 - 13 % shorter: the 64 -> 128 entry moves its 0.9 GB at 3.2 TB/s.)
 #define W4S_CV_N(Q) ((Q) == 4 ? 3 : (Q) == 8 ? 1 : 2)
 #define W4S_CV_J(Q, NN) ((Q) < 4 ? 2 * (Q) + 1 + (NN) : (Q) == 4 ? (NN) : (Q) < 8 ? 2 * (Q) - 7 + (NN) : 0)
 #define W4S_CV_DST(Q) (((Q) < 4 || (Q) == 8) ? (unsigned)STAGE : 0u)
@@ -345,25 +351,48 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
 #define W4S_LD_J(Q, NN) ((Q) == 0 ? (NN) : (Q) < 4 ? 2 * (Q) + 1 + (NN) : (Q) == 4 ? 0 : 2 * (Q) - 9 + (NN))
 #define W4S_SLOT_BODY(N)                                                                             \
         {                                                                                            \
-          if ((N) == 0 && q != 4 && q != 8) { W4_READ_X(MI - 1, 0, W4S_PLANE(q), W4S_TAPP(q), W4S_BASEOF(q)) } \
-          if ((N) >= 1 && (N) <= 9) { W4_READ_X(((N) + 8) % 9, 1, W4S_PLANE(q1), W4S_TAPP(q1), W4S_BASEOF(q1)) } \
+          if ((N) == 0) { W4_READ_X(MI - 1, 0, W4S_PLANE(q), W4S_TAPP(q), W4S_BASEOF(q)) }          \
+          if ((N) == 9 && (q == 4 || q == 8)) {                                                      \
+            /* every wave has stored its part of the buffer read next and has read its last fragments of the other one (slot 0: nine \
+               MFMAs ago - nothing is waited for but the other waves) */                             \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
+            __builtin_amdgcn_s_barrier();                                                            \
+            asm volatile("" ::: "memory");                                                           \
+            if (q == 8 && sl == 0) {                                                                 \
+              int nv;                                                                                \
+              asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nv) : "v"(slot_addr) : "memory"); \
+              next_tile = __builtin_amdgcn_readfirstlane(nv);                                        \
+              w_row_next = (unsigned)((next_tile % tiles_n) * NCB) * (unsigned)n_chunks * 4096u;     \
+            }                                                                                        \
+          }                                                                                          \
+          if ((N) >= 1 && (N) <= 9 && q != 4 && q != 8) { W4_READ_X(((N) + 8) % 9, 1, W4S_PLANE(q1), W4S_TAPP(q1), W4S_BASEOF(q1)) } \
+          if ((N) >= 10 && (N) <= 18 && (q == 4 || q == 8)) { W4_READ_X(((N) + 8) % 9, 1, W4S_PLANE(q1), W4S_TAPP(q1), W4S_BASEOF(q1)) } \
           if ((N) >= 19 && (N) <= 26) { W4_READ_X(((N) + 8) % 9, 0, W4S_PLANE(q1), W4S_TAPP(q1), W4S_BASEOF(q1)) } \
           if (((N) == 10 || (N) == 11) && qd < 9) { W4_LOAD_W(qd % W4_NSET, (N) & 1, (sl >> 1) * 9 + W4S_TAPO(qd), sl & 1, w_row) } \
           if (((N) == 10 || (N) == 11) && qd >= 9) { W4_LOAD_W(qd % W4_NSET, (N) & 1, (sl_after >> 1) * 9 + W4S_TAPO(qd - 9), sl_after & 1, row_after) } \
-          if ((N) >= 12 && (N) <= 17 && ((N) & 1) == 0 && ((N) - 12) / 2 < W4S_CV_N(q)) {            \
-            const float4 v_ = stg[W4S_CV_J(q, ((N) - 12) / 2) % 9];                                  \
-            w4_split_pair(v_.x, v_.y, x_scale, cv0, cv1);                                            \
+          /* a conversion in four slots of four vector instructions: (x, y) first pieces, their remainders, (z, w) likewise + the stores */ \
+          if ((N) >= 10 && (N) <= 21 && ((N) - 10) / 4 < W4S_CV_N(q)) {                              \
+            const float4 v_ = stg[W4S_CV_J(q, ((N) - 10) / 4) % 9];                                  \
+            constexpr int part_ = ((N) - 10) & 3;                                                    \
+            if (part_ == 0 || part_ == 2) {                                                          \
+              const f16x2w h_ = __builtin_bit_cast(f16x2w, __builtin_amdgcn_cvt_pkrtz((part_ ? v_.z : v_.x) * x_scale, (part_ ? v_.w : v_.y) * x_scale)); \
+              (part_ ? cvh1 : cvh0) = __builtin_bit_cast(unsigned, h_);                              \
+              cvf = (float)h_[0];                                                                    \
+            } else {                                                                                 \
+              const f16x2w h_ = __builtin_bit_cast(f16x2w, part_ == 1 ? cvh0 : cvh1);                \
+              const float ra_ = __builtin_fmaf(part_ == 1 ? v_.x : v_.z, x_scale, -cvf);             \
+              const float rb_ = __builtin_fmaf(part_ == 1 ? v_.y : v_.w, x_scale, -(float)h_[1]);    \
+              const unsigned p_ = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra_, rb_)); \
+              if (part_ == 1) cvp0 = p_;                                                             \
+              else {                                                                                 \
+                *reinterpret_cast<u32x2w*>(smem + W4S_CV_DST(q) + h_wa[W4S_CV_J(q, ((N) - 10) / 4) % 9]) = u32x2w{cvh0, cvh1}; \
+                *reinterpret_cast<u32x2w*>(smem + W4S_CV_DST(q) + h_wa[W4S_CV_J(q, ((N) - 10) / 4) % 9] + NHG * GSTRIDE) = u32x2w{cvp0, p_}; \
+              }                                                                                      \
+            }                                                                                        \
           }                                                                                          \
-          if ((N) >= 12 && (N) <= 17 && ((N) & 1) == 1 && ((N) - 12) / 2 < W4S_CV_N(q)) {            \
-            const float4 v_ = stg[W4S_CV_J(q, ((N) - 12) / 2) % 9];                                  \
-            unsigned a1_, b1_;                                                                       \
-            w4_split_pair(v_.z, v_.w, x_scale, a1_, b1_);                                            \
-            *reinterpret_cast<u32x2w*>(smem + W4S_CV_DST(q) + h_wa[W4S_CV_J(q, ((N) - 12) / 2) % 9]) = u32x2w{cv0, a1_}; \
-            *reinterpret_cast<u32x2w*>(smem + W4S_CV_DST(q) + h_wa[W4S_CV_J(q, ((N) - 12) / 2) % 9] + NHG * GSTRIDE) = u32x2w{cv1, b1_}; \
-          }                                                                                          \
-          if (((N) == 18 || (N) == 21 || (N) == 24) && ((N) - 18) / 3 < W4S_LD_N(q))                 \
-            stg[W4S_LD_J(q, ((N) - 18) / 3) % 9] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(    \
-                a_rsrc, h_in[W4S_LD_J(q, ((N) - 18) / 3) % 9] + (q < 4 ? hb_a : hb_b), f_soff, 0));  \
+          if ((N) >= 22 && (N) <= 24 && (N) - 22 < W4S_LD_N(q))                                      \
+            stg[W4S_LD_J(q, (N) - 22) % 9] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(    \
+                a_rsrc, h_in[W4S_LD_J(q, (N) - 22) % 9] + (q < 4 ? hb_a : hb_b), f_soff, 0));        \
           if ((N) == 16 && q == 1 && sl == 0 && tid == 0) *reinterpret_cast<int*>(smem + SLOT) = grid + ticket; \
           W4_PIN();                                                                                  \
           W4_MFMA(ws, N);                                                                            \
@@ -372,21 +401,9 @@ __global__ __launch_bounds__(256, 1) void conv_w4_kernel(ConvLaunch p, int tiles
 #define W4S_SLICE()                                                                                  \
       _Pragma("clang loop unroll(full)") for (int q = 0; q < 9; ++q) {                               \
         const int ws = q % W4_NSET;                                                                  \
-        unsigned cv0 = 0, cv1 = 0;                                                                   \
+        unsigned cvh0 = 0, cvh1 = 0, cvp0 = 0;     /* the conversion in progress */                  \
+        float cvf = 0.f;                                                                             \
         const int q1 = (q + 1) % 9, qd = q + W4_DIST;                                                \
-        if (q == 4 || q == 8) {                                                                      \
-          /* every wave has stored its part of the buffer read next and has read its last fragments of the other one */ \
-          W4_READ_X(MI - 1, 0, W4S_PLANE(q), W4S_TAPP(q), W4S_BASEOF(q))                             \
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
-          __builtin_amdgcn_s_barrier();                                                              \
-          asm volatile("" ::: "memory");                                                             \
-          if (q == 8 && sl == 0) {                                                                   \
-            int nv;                                                                                  \
-            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nv) : "v"(slot_addr) : "memory"); \
-            next_tile = __builtin_amdgcn_readfirstlane(nv);                                          \
-            w_row_next = (unsigned)((next_tile % tiles_n) * NCB) * (unsigned)n_chunks * 4096u;       \
-          }                                                                                          \
-        }                                                                                            \
         W4S_SLOT_BODY(0) W4S_SLOT_BODY(1) W4S_SLOT_BODY(2) W4S_SLOT_BODY(3) W4S_SLOT_BODY(4) W4S_SLOT_BODY(5) W4S_SLOT_BODY(6) W4S_SLOT_BODY(7) W4S_SLOT_BODY(8) \
         W4S_SLOT_BODY(9) W4S_SLOT_BODY(10) W4S_SLOT_BODY(11) W4S_SLOT_BODY(12) W4S_SLOT_BODY(13) W4S_SLOT_BODY(14) W4S_SLOT_BODY(15) W4S_SLOT_BODY(16) W4S_SLOT_BODY(17) \
         W4S_SLOT_BODY(18) W4S_SLOT_BODY(19) W4S_SLOT_BODY(20) W4S_SLOT_BODY(21) W4S_SLOT_BODY(22) W4S_SLOT_BODY(23) W4S_SLOT_BODY(24) W4S_SLOT_BODY(25) W4S_SLOT_BODY(26) \

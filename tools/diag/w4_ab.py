@@ -27,12 +27,14 @@ ho = hw // stride
 ABL = {
     "nostore": [("            __builtin_amdgcn_raw_buffer_store_b32(o, o_rsrc, off, 0, 0);", "            if (p.k_pad < 0) __builtin_amdgcn_raw_buffer_store_b32(o, o_rsrc, off, 0, 0);")],
     "nores": [("__builtin_amdgcn_raw_buffer_load_b32(r_rsrc, off, 0, 0)", "__builtin_amdgcn_raw_buffer_load_b32(r_rsrc, W4_HOOB, 0, 0)")],
-    "nowload": [("    wf[SET][(IDX) / 2][(IDX) % 2] = __builtin_bit_cast(", "    if (p.k_pad < 0) wf[SET][(IDX) / 2][(IDX) % 2] = __builtin_bit_cast(")],
-    "nopatch": [("          if ((N) == 12 && q < W4_NLOAD)  ", "          if ((N) == 12 && q < W4_NLOAD && p.k_pad < 0)  "),
-                ("          if ((N) == 14 && q >= 4 && q < 4 + W4_NLOAD) {", "          if ((N) == 14 && q >= 4 && q < 4 + W4_NLOAD && p.k_pad < 0) {")],
-    "noxread": [("    xp[SET][I][0] = *reinterpret_cast<const u32x4w*>(smem + a0_);", "    if (p.k_pad < 0) xp[SET][I][0] = *reinterpret_cast<const u32x4w*>(smem + a0_);"),
-                ("    xp[SET][I][1] = *reinterpret_cast<const u32x4w*>(smem + (a0_ ^ 64u));", "    if (p.k_pad < 0) xp[SET][I][1] = *reinterpret_cast<const u32x4w*>(smem + (a0_ ^ 64u));")],
-    "nobarrier": [("          __builtin_amdgcn_s_barrier();\n", "          if (p.k_pad < 0) __builtin_amdgcn_s_barrier();\n")],
+    "nowload": [("    wf[SET][PL] = __builtin_bit_cast(", "    if (p.k_pad < 0) wf[SET][PL] = __builtin_bit_cast(")],
+    "nopatch": [("          if ((N) == 14 && q < W4_NLOAD)  ", "          if ((N) == 14 && q < W4_NLOAD && p.k_pad < 0)  "),
+                ("          if ((N) == 13 && q >= 4 && q < 4 + W4_NLOAD) {", "          if ((N) == 13 && q >= 4 && q < 4 + W4_NLOAD && p.k_pad < 0) {")],
+    "noxread": [("  xp[I][PC] = *reinterpret_cast<const u32x4w*>(smem + (BASE)[I]", "  if (p.k_pad < 0) xp[I][PC] = *reinterpret_cast<const u32x4w*>(smem + (BASE)[I]")],
+    "s2noload": [("          if ((N) >= 22 && (N) <= 24 && (N) - 22 < W4S_LD_N(q))  ", "          if ((N) >= 22 && (N) <= 24 && (N) - 22 < W4S_LD_N(q) && p.k_pad < 0)  ")],
+    "s2nocv": [("          if ((N) >= 10 && (N) <= 21 && ((N) - 10) / 4 < W4S_CV_N(q)) {  ", "          if ((N) >= 10 && (N) <= 21 && ((N) - 10) / 4 < W4S_CV_N(q) && p.k_pad < 0) {  ")],
+    "s2nobarrier": [("            __builtin_amdgcn_s_barrier();                                                            \\\n", "            if (p.k_pad < 0) __builtin_amdgcn_s_barrier();                                                            \\\n")],
+    "nobarrier": [("          __builtin_amdgcn_s_barrier();                                                              \\\n", "          if (p.k_pad < 0) __builtin_amdgcn_s_barrier();                                                              \\\n")],
 }
 STAMP = ('if (n_done == 3) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(st_[I]) :: "memory"); '
          '__builtin_amdgcn_sched_barrier(0); }')
