@@ -194,6 +194,8 @@ def main():
                        "tolerance": "BASELINE.json north_star: 1e-4 rad / 1e-3 mm"}
 
     roofline = None
+    # (split arithmetic requested; with the roofline pass: requested AND its launches were seen)
+    split_kind = args.conv != "fp32"
     if not args.no_roofline:
         # separate profiling pass: hipEvents around every conv_igemm launch on the launch stream
         eng.profile_begin()
