@@ -611,7 +611,7 @@ bool conv_w4_applicable(const ConvLaunch& c) {
                       (size_t)c.n_img * c.Ho * c.Wo * c.cout_store * sizeof(float) < 0x7FFFFF00ull;
   if (!common) return false;
   if (c.stride == 2)      // phase planes
-    return !(c.no_resident & 8) && c.cin >= 32 && c.cout_store % 128 == 0 && c.H == 2 * c.Ho && c.W == 2 * c.Wo && !c.res &&
+    return !(c.no_resident & 8) && c.cin >= 64 /* (what the tests cover: 64 and 128; two-slice tiles are untested) */ && c.cout_store % 128 == 0 && c.H == 2 * c.Ho && c.W == 2 * c.Wo && !c.res &&
            ((c.Wo == 12 && c.Ho == 12) || (c.Wo == 6 && c.Ho == 6));
   if (c.stride != 1 || c.cin < 64 || c.H != c.Ho || c.W != c.Wo) return false;
   if (c.cout_store % 128 == 0) return (c.W == 12 && c.H == 12) || (c.W == 6 && c.H == 6);
